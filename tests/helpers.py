@@ -1,0 +1,79 @@
+"""Shared test helpers: fixture loading, input regeneration, gradient digests."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import dgvit_oracle as O  # noqa: E402  (tests are allowed to import the oracle)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def fixture_cfg(fx):
+    d = fx["meta/dims"]
+    return O.GoTConfig(image=tuple(int(v) for v in fx["meta/image"]), patch=tuple(int(v) for v in fx["meta/patch"]),
+                       dim=int(d[0]), depth=int(d[1]), heads=int(d[2]), dim_head=int(d[3]), mlp_dim=int(d[4]))
+
+
+def got_case_inputs(fx, cfg, with_mask):
+    """Regenerate exactly what make_golden.case_got fed the reference."""
+    batch, seed = int(fx["meta/batch"]), int(fx["meta/seed"])
+    img, _, _, _ = O.make_inputs(cfg, batch, seed)
+    rs = np.random.RandomState(seed + 7)
+    goal = torch.from_numpy(rs.standard_normal((batch, cfg.dim))).float()
+    wout = torch.from_numpy(rs.standard_normal((batch, cfg.dim))).float()
+    mask = None
+    if with_mask:
+        mask = torch.from_numpy((rs.random_sample((batch, cfg.tokens, cfg.dim)) < 0.9).astype(np.float32))
+    return img, goal, wout, mask
+
+
+def grad_digest(named_grads):
+    """Same digest as make_golden.grad_summary, from a dict name -> grad tensor (or None)."""
+    out = {}
+    for k, g in named_grads.items():
+        if g is None:
+            out[("none", k)] = None
+            continue
+        g = g.detach().double().flatten().cpu()
+        out[("norm", k)] = g.norm().item()
+        out[("sum", k)] = g.sum().item()
+        out[("head", k)] = g[:16].float().numpy()
+    return out
+
+
+def check_grad_digest(fx, tag, named_grads, rtol, atol, strip=""):
+    """Compare gradients with the reference digest stored under ``tag`` in fixture ``fx``."""
+    dig = grad_digest(named_grads)
+    n_checked = 0
+    for key in fx:
+        if not key.startswith(tag + "/"):
+            continue
+        _, kind, pname = key.split("/", 2)
+        ours = dig.get((kind, pname[len(strip):] if strip and pname.startswith(strip) else pname), "missing")
+        assert not isinstance(ours, str), f"no gradient entry for {pname}"
+        if kind == "none":
+            assert ours is None or float(np.abs(named_grads[pname]).max()) == 0.0, f"{pname} should have no grad"
+            continue
+        assert ours is not None, f"{pname}: reference has a gradient, we have none"
+        ref = fx[key]
+        scale = float(fx[f"{tag}/norm/{pname}"])
+        if kind == "head":
+            np.testing.assert_allclose(ours, ref, rtol=rtol, atol=atol * max(1.0, scale), err_msg=key)
+        elif kind == "norm":
+            np.testing.assert_allclose(ours, ref, rtol=rtol, atol=atol, err_msg=key)
+        else:  # sum: cancellation-prone, scale tolerance by the norm and sqrt(numel)
+            np.testing.assert_allclose(ours, ref, rtol=rtol, atol=atol * max(1.0, scale) * 64, err_msg=key)
+        n_checked += 1
+    assert n_checked > 0
+    return n_checked
