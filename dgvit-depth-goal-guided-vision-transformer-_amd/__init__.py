@@ -1,0 +1,12 @@
+"""dgvit_amd -- MI355X-native DGViT encoder hot path.
+
+Python host code over the C ABI of libdgvit_hip.so (include/dgvit_hip.h).  Importing the package never
+touches the GPU; the first call loads the library and raises ``DgvitError`` if it is missing.
+"""
+from ._lib import DgvitError, LIB_PATH, load as load_library  # noqa: F401
+from .goalformer import GoT  # noqa: F401
+from .sac_networks import GoTPolicy, GoTQNetwork, DeterministicGoTPolicy, weights_init_  # noqa: F401
+from . import functional  # noqa: F401
+
+__all__ = ["GoT", "GoTPolicy", "GoTQNetwork", "DeterministicGoTPolicy", "weights_init_", "functional", "DgvitError",
+           "load_library", "LIB_PATH"]

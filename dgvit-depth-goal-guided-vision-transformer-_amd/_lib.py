@@ -1,0 +1,85 @@
+"""ctypes binding of libdgvit_hip.so (C ABI: include/dgvit_hip.h).
+
+There is no CPU or PyTorch fallback: if the shared library is missing or a call fails, a
+``DgvitError`` is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_ulonglong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdgvit_hip.so")
+
+
+class DgvitError(RuntimeError):
+    pass
+
+
+class dgvit_config(Structure):
+    _fields_ = [("image_h", c_int), ("image_w", c_int), ("patch_h", c_int), ("patch_w", c_int), ("dim", c_int),
+                ("depth", c_int), ("heads", c_int), ("dim_head", c_int), ("mlp_dim", c_int)]
+
+
+NUM_GLOBAL_PARAMS = 4
+PARAMS_PER_LAYER = 11
+ABI_VERSION = 1
+
+_P, _I, _LL, _F, _ULL = c_void_p, c_int, c_longlong, c_float, c_ulonglong
+_CFG = POINTER(dgvit_config)
+_TABLE = POINTER(c_void_p)
+
+# name -> (restype, argtypes); every symbol include/dgvit_hip.h declares
+SIGNATURES = {
+    "dgvit_abi_version": (_I, []),
+    "dgvit_last_error": (c_char_p, []),
+    "dgvit_device_count": (_I, []),
+    "dgvit_got_workspace_floats": (_LL, [_CFG, _I, _I]),
+    "dgvit_got_backward_scratch_floats": (_LL, [_CFG, _I]),
+    "dgvit_got_forward": (_I, [_CFG, _TABLE, _P, _P, _P, _P, _LL, _I, _I, _F, _ULL, _P]),
+    "dgvit_got_backward": (_I, [_CFG, _TABLE, _TABLE, _P, _P, _P, _LL, _P, _LL, _I, _F, _ULL, _P]),
+    "dgvit_linear_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dgvit_linear_backward_scratch_floats": (_LL, [_I, _I, _I]),
+    "dgvit_linear_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
+    "dgvit_gemm_scratch_floats": (_LL, [_I, _I, _I, _I]),
+    "dgvit_gemm": (_I, [_I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P, _LL, _P]),
+    "dgvit_set_gemm_tile": (None, [_I]),
+    "dgvit_layernorm_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "dgvit_layernorm_backward_scratch_floats": (_LL, [_I, _I]),
+    "dgvit_layernorm_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _P]),
+    "dgvit_rmsnorm_forward": (_I, [_P, _LL, _P, _P, _I, _I, _P]),
+    "dgvit_rmsnorm_backward_scratch_floats": (_LL, [_I, _I]),
+    "dgvit_rmsnorm_backward": (_I, [_P, _P, _LL, _P, _P, _LL, _P, _P, _LL, _I, _I, _P]),
+    "dgvit_attention_forward": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dgvit_attention_backward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dgvit_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "dgvit_dropout": (_I, [_P, _LL, _ULL, _F, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the shared library; raise DgvitError if it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DgvitError(f"{LIB_PATH} not found: build it with `python {os.path.join(_HERE, 'build.py')}` "
+                         "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DgvitError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.dgvit_abi_version() != ABI_VERSION:
+        raise DgvitError(f"ABI mismatch: library {lib.dgvit_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().dgvit_last_error()
+        raise DgvitError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")

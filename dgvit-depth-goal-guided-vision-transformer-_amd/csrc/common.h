@@ -1,0 +1,79 @@
+// Shared declarations for the DGViT gfx950 kernels (internal; the public C ABI is include/dgvit_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dgvit_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DGVIT_WAVE 64
+
+// ---- error reporting (thread-local message, negative return codes from include/dgvit_hip.h) ------
+int dgvit_set_error(int code, const char* fmt, ...);
+
+#define DGVIT_CHECK_ARG(cond, ...)                                   \
+  do {                                                               \
+    if (!(cond)) return dgvit_set_error(DGVIT_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+
+#define DGVIT_CHECK_LAUNCH(name)                                                                 \
+  do {                                                                                           \
+    hipError_t e_ = hipGetLastError();                                                           \
+    if (e_ != hipSuccess) return dgvit_set_error(DGVIT_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- GEMM -----------------------------------------------------------------------------------
+// C[m][n] = sum_k Aop[m][k] * Bop[k][n]   (fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32)
+enum GemmLayout {
+  GEMM_NT = 0,  // A [M][K] (k contiguous), B [N][K] (k contiguous)   forward:  Y = X W^T
+  GEMM_NN = 1,  // A [M][K] (k contiguous), B [K][N] (n contiguous)   dgrad:    dX = dY W
+  GEMM_TN = 2   // A [K][M] (m contiguous), B [K][N] (n contiguous)   wgrad:    dW = dY^T X
+};
+
+enum GemmEpilogue {
+  EPI_STORE = 0,   // C = acc (+ bias[n]) (+ res[rr][n]),  optional output-row remap
+  EPI_GELU2 = 1,   // C = acc + bias ; C2 = gelu_erf(C)
+  EPI_DGELU = 2,   // C = acc * gelu'(aux[m][n])
+  EPI_RELU = 3,    // C = max(acc + bias, 0)
+  EPI_DRELU = 4,   // C = aux[m][n] > 0 ? acc : 0
+  EPI_SPLITK = 5   // C = slab[z][m][n] = acc   (reduced later by dgvit_reduce_slabs)
+};
+
+struct GemmParams {
+  const float* A; const float* B;
+  int lda, ldb;
+  int M, N, K;
+  int kchunk;            // K range handled by one blockIdx.z (multiple of BK); == K when not split
+  int a_kgrp;            // TN only: physical A row = k + k / a_kgrp + 1 when a_kgrp > 0 (token rows of patch rows)
+  float* C; int ldc;
+  const float* bias;     // [N] or null
+  const float* res; int ldr;  // residual [*][N] or null
+  int res_mod;           // > 0: residual row = (m % res_mod) + 1  (positional embedding broadcast over frames)
+  float* C2; int ldc2;   // second output (EPI_GELU2)
+  const float* aux; int ldaux;  // EPI_DGELU / EPI_DRELU input
+  int c_rgrp;            // > 0: physical C row = m + m / c_rgrp + 1
+  long long slab_stride; // EPI_SPLITK: floats between consecutive z slabs
+};
+
+int gemm_f32(int layout, int epi, const GemmParams& p, int nsplit, hipStream_t stream);
+int reduce_slabs(const float* slabs, float* out, long long n, int nslab, long long slab_stride, hipStream_t stream);
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

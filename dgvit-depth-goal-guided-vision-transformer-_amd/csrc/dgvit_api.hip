@@ -1,0 +1,460 @@
+// extern "C" surface of libdgvit_hip.so (include/dgvit_hip.h) and the encoder forward/backward schedules.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/dgvit_hip.h"
+#include "common.h"
+
+// kernels implemented in the other translation units
+int layernorm_fwd(const float*, const float*, const float*, float*, float*, float*, int, int, float, hipStream_t);
+int layernorm_bwd_blocks(int T);
+int layernorm_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*,
+                  float*, int, int, hipStream_t);
+int rmsnorm_fwd(const float*, long long, const float*, float*, int, int, hipStream_t);
+int rmsnorm_bwd_blocks(int B);
+int rmsnorm_bwd(const float*, const float*, long long, const float*, float*, long long, float*, float*, int, int, hipStream_t);
+int colsum_blocks(int T);
+int colsum(const float*, long long, float*, float*, int, int, int, hipStream_t);
+int attention_fwd(const float*, float*, int, int, int, int, hipStream_t);
+int attention_bwd(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
+int patchify(const float*, float*, int, int, int, int, int, hipStream_t);
+int goal_row(const float*, const float*, float*, int, int, int, hipStream_t);
+int dropout_inplace(float*, long long, unsigned long long, float, hipStream_t);
+int relu_bwd(const float*, const float*, float*, long long, hipStream_t);
+extern int g_gemm_tile_hint;
+
+// ---------------------------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+
+int dgvit_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define TRY(expr)          \
+  do {                     \
+    int rc_ = (expr);      \
+    if (rc_) return rc_;   \
+  } while (0)
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return dgvit_set_error(DGVIT_ERR_HIP, #expr ": %s", hipGetErrorString(e_)); \
+  } while (0)
+
+static inline long long al4(long long n) { return (n + 3) & ~3ll; }
+
+// ---------------------------------------------------------------------------------------------- GEMM helpers
+namespace {
+
+GemmParams gp(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K) {
+  GemmParams p = {};
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.kchunk = (K + 31) / 32 * 32;
+  return p;
+}
+
+// split-K plan for weight gradients: enough workgroups to cover the chip a few times over
+int wgrad_splits(int M, int N, int K) {
+  const int bt = (M >= 128 && N >= 128) ? 128 : 64;
+  const long long tiles = (long long)((M + bt - 1) / bt) * ((N + bt - 1) / bt);
+  long long s = (1024 + tiles - 1) / tiles;
+  const long long maxs = (K + 255) / 256;  // at least 8 k-tiles per split
+  if (s > maxs) s = maxs;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+long long wgrad_scratch(int M, int N, int K) { return (long long)wgrad_splits(M, N, K) * al4((long long)M * N); }
+
+// dW (M x N) = A^T B with A (K x M, lda), B (K x N, ldb); a_kgrp remaps A's rows (see GemmParams)
+int wgrad(const float* A, int lda, const float* B, int ldb, float* dW, int M, int N, int K, int a_kgrp, float* scratch,
+          long long scratch_floats, hipStream_t st) {
+  const int ns = wgrad_splits(M, N, K);
+  const long long slab = al4((long long)M * N);
+  if (scratch_floats < ns * slab) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "wgrad: scratch %lld < %lld floats", scratch_floats, ns * slab);
+  GemmParams p = gp(A, lda, B, ldb, scratch, N, M, N, K);
+  p.a_kgrp = a_kgrp;
+  const int kt = (K + 31) / 32;
+  p.kchunk = ((kt + ns - 1) / ns) * 32;
+  p.slab_stride = slab;
+  const int ns_eff = (K + p.kchunk - 1) / p.kchunk;
+  TRY(gemm_f32(GEMM_TN, EPI_SPLITK, p, ns_eff, st));
+  return reduce_slabs(scratch, dW, (long long)M * N, ns_eff, slab, st);
+}
+
+struct Dims {
+  int B, P, N, D, I, M, L, H, dh, pd;
+  long long T;
+};
+
+int make_dims(const dgvit_config* c, int batch, Dims& d) {
+  DGVIT_CHECK_ARG(c, "null config");
+  DGVIT_CHECK_ARG(batch > 0, "batch must be positive");
+  DGVIT_CHECK_ARG(c->patch_h > 0 && c->patch_w > 0 && c->image_h > 0 && c->image_w > 0 && c->image_h % c->patch_h == 0 &&
+                      c->image_w % c->patch_w == 0,
+                  "Image dimensions must be divisible by the patch size.");
+  DGVIT_CHECK_ARG(c->dim > 0 && c->dim % 4 == 0 && c->dim <= 1024, "dim=%d must be a multiple of 4 and <= 1024", c->dim);
+  DGVIT_CHECK_ARG(c->depth > 0 && c->heads > 0 && c->mlp_dim > 0 && c->mlp_dim % 4 == 0, "bad depth/heads/mlp_dim");
+  DGVIT_CHECK_ARG(c->dim_head == 64 || c->dim_head == 32, "dim_head=%d unsupported (64 or 32)", c->dim_head);
+  d.B = batch;
+  d.P = (c->image_h / c->patch_h) * (c->image_w / c->patch_w);
+  d.N = d.P + 1;
+  d.D = c->dim; d.H = c->heads; d.dh = c->dim_head; d.I = d.H * d.dh; d.M = c->mlp_dim; d.L = c->depth;
+  d.pd = c->patch_h * c->patch_w;
+  d.T = (long long)batch * d.N;
+  DGVIT_CHECK_ARG(d.N <= (d.dh == 64 ? 224 : 64), "tokens N=%d exceeds the fused-attention limit", d.N);
+  DGVIT_CHECK_ARG(d.T < (1ll << 31) && d.T * (long long)(3 * d.I > d.M ? 3 * d.I : d.M) < (1ll << 40), "batch too large");
+  return DGVIT_OK;
+}
+
+// activation workspace carve-up (floats); `save` keeps per-layer buffers distinct
+struct Ws {
+  long long patches, x0, layer0, layer_stride, layer_floats, total;
+  // per-layer offsets relative to the layer base
+  long long mean1, rstd1, ln1, qkv, ao, xmid, mean2, rstd2, ln2, h1, a1, xout;
+};
+
+Ws make_ws(const Dims& d, int save) {
+  Ws w;
+  long long o = 0;
+  w.patches = o; o += al4((long long)d.B * d.P * d.pd);
+  w.x0 = o; o += al4(d.T * d.D);
+  long long l = 0;
+  w.mean1 = l; l += al4(d.T);
+  w.rstd1 = l; l += al4(d.T);
+  w.ln1 = l; l += al4(d.T * d.D);
+  w.qkv = l; l += al4(d.T * 3 * d.I);
+  w.ao = l; l += al4(d.T * d.I);
+  w.xmid = l; l += al4(d.T * d.D);
+  w.mean2 = l; l += al4(d.T);
+  w.rstd2 = l; l += al4(d.T);
+  w.ln2 = l; l += al4(d.T * d.D);
+  w.h1 = l; l += al4(d.T * d.M);
+  w.a1 = l; l += al4(d.T * d.M);
+  w.xout = l; l += al4(d.T * d.D);
+  w.layer0 = o;
+  w.layer_floats = l;
+  if (save) {
+    w.layer_stride = l;
+    o += l * d.L;
+  } else {
+    // inference: one shared set of temporaries; odd layers write their output into one extra
+    // residual-stream buffer placed right behind it, even layers into the shared `xout`
+    w.layer_stride = 0;
+    o += l + al4(d.T * d.D);
+  }
+  w.total = o;
+  return w;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- misc exports
+extern "C" int dgvit_abi_version(void) { return DGVIT_ABI_VERSION; }
+extern "C" const char* dgvit_last_error(void) { return g_err; }
+extern "C" int dgvit_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+extern "C" void dgvit_set_gemm_tile(int tile) { g_gemm_tile_hint = tile; }
+
+// ---------------------------------------------------------------------------------------------- encoder
+extern "C" long long dgvit_got_workspace_floats(const dgvit_config* cfg, int batch, int save) {
+  Dims d;
+  if (make_dims(cfg, batch, d)) return -1;
+  return make_ws(d, save).total;
+}
+
+namespace {
+struct Bs {  // backward scratch carve-up
+  long long dxa, dxb, dln, dqkv, dao, dh1, part, slabs, total, slabs_floats;
+};
+Bs make_bs(const Dims& d) {
+  Bs s;
+  long long o = 0;
+  s.dxa = o; o += al4(d.T * d.D);
+  s.dxb = o; o += al4(d.T * d.D);
+  s.dln = o; o += al4(d.T * d.D);
+  s.dqkv = o; o += al4(d.T * 3 * d.I);
+  s.dao = o; o += al4(d.T * d.I);
+  s.dh1 = o; o += al4(d.T * d.M);
+  // reduction partials: LN (blocks*2*D), colsum (blocks*max width), rms, dpos (blocks * N*D)
+  long long part = (long long)layernorm_bwd_blocks((int)d.T) * 2 * d.D;
+  const long long widest = (long long)(d.M > 3 * d.I ? d.M : 3 * d.I);
+  const long long cs = (long long)colsum_blocks((int)d.T) * widest;
+  if (cs > part) part = cs;
+  const long long dp = (long long)colsum_blocks(d.B) * d.N * d.D;
+  if (dp > part) part = dp;
+  const long long rp = (long long)rmsnorm_bwd_blocks(d.B) * d.D;
+  if (rp > part) part = rp;
+  s.part = o; o += al4(part);
+  long long sl = wgrad_scratch(3 * d.I, d.D, (int)d.T);
+  long long t;
+  if ((t = wgrad_scratch(d.D, d.I, (int)d.T)) > sl) sl = t;
+  if ((t = wgrad_scratch(d.M, d.D, (int)d.T)) > sl) sl = t;
+  if ((t = wgrad_scratch(d.D, d.M, (int)d.T)) > sl) sl = t;
+  if ((t = wgrad_scratch(d.D, d.pd, d.B * d.P)) > sl) sl = t;
+  s.slabs = o; s.slabs_floats = sl; o += sl;
+  s.total = o;
+  return s;
+}
+}  // namespace
+
+extern "C" long long dgvit_got_backward_scratch_floats(const dgvit_config* cfg, int batch) {
+  Dims d;
+  if (make_dims(cfg, batch, d)) return -1;
+  return make_bs(d).total;
+}
+
+enum { P_POS = 0, P_PW = 1, P_PB = 2, P_RMS = 3, P_L0 = 4 };
+enum { L_LN1W = 0, L_LN1B, L_QKV, L_OUTW, L_OUTB, L_LN2W, L_LN2B, L_FC1W, L_FC1B, L_FC2W, L_FC2B };
+
+extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* params, const float* img, const float* goal,
+                                 float* feat, float* ws, long long ws_floats, int batch, int save, float keep,
+                                 unsigned long long seed, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Dims d;
+  TRY(make_dims(cfg, batch, d));
+  DGVIT_CHECK_ARG(params && img && goal && feat && ws, "dgvit_got_forward: null pointer");
+  DGVIT_CHECK_ARG(keep > 0.f && keep <= 1.f, "dropout_keep must be in (0, 1]");
+  const Ws w = make_ws(d, save);
+  if (ws_floats < w.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "forward workspace %lld < %lld floats", ws_floats, w.total);
+  for (int i = 0; i < P_L0 + DGVIT_PARAMS_PER_LAYER * d.L; ++i) DGVIT_CHECK_ARG(params[i], "parameter %d is null", i);
+  const int T = (int)d.T;
+
+  // patch embedding (GoalFormer.py:137-139,157) + goal token, positional embedding, dropout (:160-163)
+  float* patches = ws + w.patches;
+  float* x = ws + w.x0;
+  TRY(patchify(img, patches, d.B, cfg->image_h, cfg->image_w, cfg->patch_h, cfg->patch_w, st));
+  {
+    GemmParams p = gp(patches, d.pd, params[P_PW], d.pd, x, d.D, d.B * d.P, d.D, d.pd);
+    p.bias = params[P_PB];
+    p.res = params[P_POS]; p.ldr = d.D; p.res_mod = d.P;  // + pos_embedding[1 + patch]
+    p.c_rgrp = d.P;                                       // row (b, patch) -> token row b*N + 1 + patch
+    TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
+  }
+  TRY(goal_row(goal, params[P_POS], x, d.B, d.N, d.D, st));
+  if (keep < 1.f) TRY(dropout_inplace(x, d.T * d.D, seed, keep, st));
+
+  for (int i = 0; i < d.L; ++i) {
+    const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
+    float* lb = ws + w.layer0 + w.layer_stride * i;
+    float* xo = (save || !(i & 1)) ? lb + w.xout : ws + w.layer0 + w.layer_floats;
+    // x = attn(LN(x)) + x   (GoalFormer.py:103, 36-37, 71-82)
+    TRY(layernorm_fwd(x, lp[L_LN1W], lp[L_LN1B], lb + w.ln1, lb + w.mean1, lb + w.rstd1, T, d.D, 1e-5f, st));
+    {
+      GemmParams p = gp(lb + w.ln1, d.D, lp[L_QKV], d.D, lb + w.qkv, 3 * d.I, T, 3 * d.I, d.D);
+      TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
+    }
+    TRY(attention_fwd(lb + w.qkv, lb + w.ao, d.B, d.N, d.H, d.dh, st));
+    {
+      GemmParams p = gp(lb + w.ao, d.I, lp[L_OUTW], d.I, lb + w.xmid, d.D, T, d.D, d.I);
+      p.bias = lp[L_OUTB]; p.res = x; p.ldr = d.D;
+      TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
+    }
+    // x = ff(LN(x)) + x     (GoalFormer.py:104, 42-50)
+    TRY(layernorm_fwd(lb + w.xmid, lp[L_LN2W], lp[L_LN2B], lb + w.ln2, lb + w.mean2, lb + w.rstd2, T, d.D, 1e-5f, st));
+    {
+      GemmParams p = gp(lb + w.ln2, d.D, lp[L_FC1W], d.D, lb + w.h1, d.M, T, d.M, d.D);
+      p.bias = lp[L_FC1B]; p.C2 = lb + w.a1; p.ldc2 = d.M;
+      TRY(gemm_f32(GEMM_NT, EPI_GELU2, p, 1, st));
+    }
+    {
+      GemmParams p = gp(lb + w.a1, d.M, lp[L_FC2W], d.M, xo, d.D, T, d.D, d.M);
+      p.bias = lp[L_FC2B]; p.res = lb + w.xmid; p.ldr = d.D;
+      TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
+    }
+    x = xo;
+  }
+  // x[:, 0] -> RMSNorm  (GoalFormer.py:167-170)
+  return rmsnorm_fwd(x, (long long)d.N * d.D, params[P_RMS], feat, d.B, d.D, st);
+}
+
+extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* params, float* const* grads, const float* dfeat,
+                                  float* dgoal, const float* ws, long long ws_floats, float* scratch, long long scratch_floats,
+                                  int batch, float keep, unsigned long long seed, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Dims d;
+  TRY(make_dims(cfg, batch, d));
+  DGVIT_CHECK_ARG(params && grads && dfeat && ws && scratch, "dgvit_got_backward: null pointer");
+  const Ws w = make_ws(d, 1);
+  const Bs s = make_bs(d);
+  if (ws_floats < w.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "backward workspace %lld < %lld floats", ws_floats, w.total);
+  if (scratch_floats < s.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "backward scratch %lld < %lld floats", scratch_floats, s.total);
+  const int np = P_L0 + DGVIT_PARAMS_PER_LAYER * d.L;
+  for (int i = 0; i < np; ++i) DGVIT_CHECK_ARG(params[i] && grads[i], "parameter/gradient %d is null", i);
+  const int T = (int)d.T;
+  float* dx = scratch + s.dxa;    // gradient of the residual stream entering the current op
+  float* dx2 = scratch + s.dxb;
+  float* dln = scratch + s.dln;
+  float* dqkv = scratch + s.dqkv;
+  float* dao = scratch + s.dao;
+  float* dh1 = scratch + s.dh1;
+  float* part = scratch + s.part;
+  float* slabs = scratch + s.slabs;
+
+  // RMSNorm on token 0 of the last layer's output; every other token row gets zero gradient
+  const float* xl = ws + w.layer0 + w.layer_stride * (d.L - 1) + w.xout;
+  HIP_TRY(hipMemsetAsync(dx, 0, sizeof(float) * d.T * d.D, st));
+  TRY(rmsnorm_bwd(dfeat, xl, (long long)d.N * d.D, params[P_RMS], dx, (long long)d.N * d.D, grads[P_RMS], part, d.B, d.D, st));
+
+  for (int i = d.L - 1; i >= 0; --i) {
+    const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
+    float* const* lg = grads + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
+    const float* lb = ws + w.layer0 + w.layer_stride * i;
+    const float* xin = i == 0 ? ws + w.x0 : ws + w.layer0 + w.layer_stride * (i - 1) + w.xout;
+    // ---- feed-forward branch: xout = fc2(gelu(fc1(ln2))) + xmid
+    TRY(colsum(dx, d.D, lg[L_FC2B], part, T, d.D, 0, st));
+    TRY(wgrad(dx, d.D, lb + w.a1, d.M, lg[L_FC2W], d.D, d.M, T, 0, slabs, s.slabs_floats, st));
+    {
+      GemmParams p = gp(dx, d.D, lp[L_FC2W], d.M, dh1, d.M, T, d.M, d.D);
+      p.aux = lb + w.h1; p.ldaux = d.M;
+      TRY(gemm_f32(GEMM_NN, EPI_DGELU, p, 1, st));  // dh1 = (dx W2) * gelu'(h1)
+    }
+    TRY(colsum(dh1, d.M, lg[L_FC1B], part, T, d.M, 0, st));
+    TRY(wgrad(dh1, d.M, lb + w.ln2, d.D, lg[L_FC1W], d.M, d.D, T, 0, slabs, s.slabs_floats, st));
+    {
+      GemmParams p = gp(dh1, d.M, lp[L_FC1W], d.D, dln, d.D, T, d.D, d.M);
+      TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dln2 = dh1 W1
+    }
+    TRY(layernorm_bwd(dln, lb + w.xmid, lb + w.mean2, lb + w.rstd2, lp[L_LN2W], dx, dx2, lg[L_LN2W], lg[L_LN2B], part, T, d.D, st));
+    // ---- attention branch: xmid = to_out(attn(to_qkv(ln1))) + xin       (dx2 = d xmid)
+    TRY(colsum(dx2, d.D, lg[L_OUTB], part, T, d.D, 0, st));
+    TRY(wgrad(dx2, d.D, lb + w.ao, d.I, lg[L_OUTW], d.D, d.I, T, 0, slabs, s.slabs_floats, st));
+    {
+      GemmParams p = gp(dx2, d.D, lp[L_OUTW], d.I, dao, d.I, T, d.I, d.D);
+      TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dao = dxmid Wo
+    }
+    TRY(attention_bwd(lb + w.qkv, lb + w.ao, dao, dqkv, d.B, d.N, d.H, d.dh, st));
+    TRY(wgrad(dqkv, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV], 3 * d.I, d.D, T, 0, slabs, s.slabs_floats, st));
+    {
+      GemmParams p = gp(dqkv, 3 * d.I, lp[L_QKV], d.D, dln, d.D, T, d.D, 3 * d.I);
+      TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dln1 = dqkv Wqkv
+    }
+    TRY(layernorm_bwd(dln, xin, lb + w.mean1, lb + w.rstd1, lp[L_LN1W], dx2, dx, lg[L_LN1W], lg[L_LN1B], part, T, d.D, st));
+  }
+  // ---- token assembly: x0 = dropout(cat(goal, patches W^T + b) + pos)
+  if (keep < 1.f) TRY(dropout_inplace(dx, d.T * d.D, seed, keep, st));
+  if (dgoal)
+    HIP_TRY(hipMemcpy2DAsync(dgoal, sizeof(float) * d.D, dx, sizeof(float) * d.N * d.D, sizeof(float) * d.D, d.B,
+                             hipMemcpyDeviceToDevice, st));
+  TRY(colsum(dx, (long long)d.N * d.D, grads[P_POS], part, d.B, d.N * d.D, 0, st));  // dpos = sum over frames
+  TRY(colsum(dx, d.D, grads[P_PB], part, d.B * d.P, d.D, d.P, st));
+  TRY(wgrad(dx, d.D, ws + w.patches, d.pd, grads[P_PW], d.D, d.pd, d.B * d.P, d.P, slabs, s.slabs_floats, st));
+  return DGVIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- head Linears
+extern "C" int dgvit_linear_forward(const float* x, const float* wt, const float* b, float* y, int M, int N, int K, int act,
+                                    void* stream) {
+  DGVIT_CHECK_ARG(act == 0 || act == 1, "linear: act must be 0 (identity) or 1 (relu)");
+  DGVIT_CHECK_ARG(x && wt && y && M > 0 && N > 0 && K > 0, "linear: bad arguments");
+  GemmParams p = gp(x, K, wt, K, y, N, M, N, K);
+  p.bias = b;
+  return gemm_f32(GEMM_NT, act ? EPI_RELU : EPI_STORE, p, 1, (hipStream_t)stream);
+}
+
+extern "C" long long dgvit_linear_backward_scratch_floats(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return -1;
+  return al4((long long)M * N) + al4((long long)colsum_blocks(M) * N) + wgrad_scratch(N, K, M);
+}
+
+extern "C" int dgvit_linear_backward(const float* dy, const float* x, const float* wt, const float* y, float* dx, float* dw,
+                                     float* db, float* scratch, long long scratch_floats, int M, int N, int K, int act,
+                                     void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DGVIT_CHECK_ARG(act == 0 || act == 1, "linear: act must be 0 (identity) or 1 (relu)");
+  DGVIT_CHECK_ARG(dy && x && wt && dw && scratch && M > 0 && N > 0 && K > 0, "linear_backward: bad arguments");
+  DGVIT_CHECK_ARG(act == 0 || y, "linear_backward: relu needs the forward output");
+  const long long need = dgvit_linear_backward_scratch_floats(M, N, K);
+  if (scratch_floats < need) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "linear_backward scratch %lld < %lld floats", scratch_floats, need);
+  float* dpre = scratch;
+  float* part = scratch + al4((long long)M * N);
+  float* slabs = part + al4((long long)colsum_blocks(M) * N);
+  const float* g = dy;
+  if (act == 1) {
+    TRY(relu_bwd(dy, y, dpre, (long long)M * N, st));
+    g = dpre;
+  }
+  if (db) TRY(colsum(g, N, db, part, M, N, 0, st));
+  TRY(wgrad(g, N, x, K, dw, N, K, M, 0, slabs, wgrad_scratch(N, K, M), st));
+  if (dx) {
+    GemmParams p = gp(g, N, wt, K, dx, K, M, K, N);
+    TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));
+  }
+  return DGVIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- operator exports
+extern "C" long long dgvit_gemm_scratch_floats(int layout, int M, int N, int K) {
+  if (layout != GEMM_TN) return 0;
+  return wgrad_scratch(M, N, K);
+}
+
+extern "C" int dgvit_gemm(int layout, int epilogue, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
+                          int N, int K, const float* bias, const float* res, int ldr, float* C2, int ldc2, const float* aux,
+                          int ldaux, float* scratch, long long scratch_floats, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == GEMM_TN) {
+    DGVIT_CHECK_ARG(epilogue == EPI_STORE && !bias && !res, "gemm: layout TN supports the plain epilogue only");
+    DGVIT_CHECK_ARG(ldc == N, "gemm: layout TN writes a dense C (ldc == N)");
+    DGVIT_CHECK_ARG(scratch, "gemm: layout TN needs scratch");
+    return wgrad(A, lda, B, ldb, C, M, N, K, 0, scratch, scratch_floats, st);
+  }
+  DGVIT_CHECK_ARG(layout == GEMM_NT || layout == GEMM_NN, "gemm: bad layout %d", layout);
+  DGVIT_CHECK_ARG(epilogue >= EPI_STORE && epilogue <= EPI_DRELU, "gemm: bad epilogue %d", epilogue);
+  DGVIT_CHECK_ARG(epilogue != EPI_GELU2 || C2, "gemm: epilogue 1 needs C2");
+  DGVIT_CHECK_ARG((epilogue != EPI_DGELU && epilogue != EPI_DRELU) || aux, "gemm: epilogue needs aux");
+  GemmParams p = gp(A, lda, B, ldb, C, ldc, M, N, K);
+  p.bias = bias; p.res = res; p.ldr = ldr; p.C2 = C2; p.ldc2 = ldc2; p.aux = aux; p.ldaux = ldaux;
+  return gemm_f32(layout, epilogue, p, 1, st);
+}
+
+extern "C" int dgvit_layernorm_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                       int rows, int D, void* stream) {
+  return layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, 1e-5f, (hipStream_t)stream);
+}
+extern "C" long long dgvit_layernorm_backward_scratch_floats(int rows, int D) {
+  if (rows <= 0 || D <= 0) return -1;
+  return (long long)layernorm_bwd_blocks(rows) * 2 * D;
+}
+extern "C" int dgvit_layernorm_backward(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                        const float* dres, float* dx, float* dgamma, float* dbeta, float* scratch,
+                                        long long scratch_floats, int rows, int D, void* stream) {
+  if (scratch_floats < dgvit_layernorm_backward_scratch_floats(rows, D))
+    return dgvit_set_error(DGVIT_ERR_WORKSPACE, "layernorm_backward: scratch too small");
+  return layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, scratch, rows, D, (hipStream_t)stream);
+}
+extern "C" int dgvit_rmsnorm_forward(const float* x, long long ldx, const float* g, float* y, int rows, int D, void* stream) {
+  return rmsnorm_fwd(x, ldx, g, y, rows, D, (hipStream_t)stream);
+}
+extern "C" long long dgvit_rmsnorm_backward_scratch_floats(int rows, int D) {
+  if (rows <= 0 || D <= 0) return -1;
+  return (long long)rmsnorm_bwd_blocks(rows) * D;
+}
+extern "C" int dgvit_rmsnorm_backward(const float* dy, const float* x, long long ldx, const float* g, float* dx, long long lddx,
+                                      float* dg, float* scratch, long long scratch_floats, int rows, int D, void* stream) {
+  if (scratch_floats < dgvit_rmsnorm_backward_scratch_floats(rows, D))
+    return dgvit_set_error(DGVIT_ERR_WORKSPACE, "rmsnorm_backward: scratch too small");
+  return rmsnorm_bwd(dy, x, ldx, g, dx, lddx, dg, scratch, rows, D, (hipStream_t)stream);
+}
+extern "C" int dgvit_attention_forward(const float* qkv, float* out, int B, int N, int H, int dh, void* stream) {
+  return attention_fwd(qkv, out, B, N, H, dh, (hipStream_t)stream);
+}
+extern "C" int dgvit_attention_backward(const float* qkv, const float* out, const float* dout, float* dqkv, int B, int N, int H,
+                                        int dh, void* stream) {
+  return attention_bwd(qkv, out, dout, dqkv, B, N, H, dh, (hipStream_t)stream);
+}
+extern "C" int dgvit_patchify(const float* img, float* patches, int B, int ih, int iw, int ph, int pw, void* stream) {
+  return patchify(img, patches, B, ih, iw, ph, pw, (hipStream_t)stream);
+}
+extern "C" int dgvit_dropout(float* x, long long n, unsigned long long seed, float keep, void* stream) {
+  return dropout_inplace(x, n, seed, keep, (hipStream_t)stream);
+}

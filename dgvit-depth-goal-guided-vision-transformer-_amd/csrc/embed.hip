@@ -1,0 +1,99 @@
+// Token assembly around the patch-embedding GEMM (GoalFormer.py:138, 160-163) and small elementwise helpers.
+//   patchify      : 'b (h p1) (w p2) -> b (h w) (p1 p2)'  (the GEMM's A operand; also kept for the weight gradient)
+//   goal_row      : x0[b, 0, :] = goal[b] + pos[0]         (goal token in the CLS slot)
+//   dropout       : in-place Bernoulli(keep) mask / keep, Philox4x32-10 keyed by (seed), counter = float4 index
+//                   -- the same call with the same seed re-creates the mask in backward, nothing is stored
+//   relu_bwd      : dpre = dy * (y > 0)                    (head MLPs)
+#include "common.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) patchify_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int Hi, int Wi,
+                                                       int ph, int pw) {
+  const int gw = Wi / pw, gh = Hi / ph, pd = ph * pw;
+  const long long total = (long long)B * gh * gw * pd;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int e = (int)(idx % pd);
+  const long long bp = idx / pd;
+  const int p = (int)(bp % (gh * gw));
+  const long long b = bp / (gh * gw);
+  const int p1 = e / pw, p2 = e % pw, hy = p / gw, wx = p % gw;
+  out[idx] = img[(b * Hi + hy * ph + p1) * Wi + wx * pw + p2];
+}
+
+__global__ void __launch_bounds__(256) goal_row_kernel(const float* __restrict__ goal, const float* __restrict__ pos,
+                                                       float* __restrict__ x0, int B, int N, int D) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)B * D) return;
+  const int d = (int)(idx % D);
+  const long long b = idx / D;
+  x0[b * N * D + d] = goal[idx] + pos[d];
+}
+
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+    const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+    key.x += W0;
+    key.y += W1;
+  }
+  return ctr;
+}
+
+__global__ void __launch_bounds__(256) dropout_kernel(float* __restrict__ x, long long n4, unsigned long long seed, float keep) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)(i >> 32), 0u, 0u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+  const float inv = 1.0f / keep;
+  const float sc = 2.3283064365386963e-10f;  // 2^-32
+  float4 v = reinterpret_cast<float4*>(x)[i];
+  v.x = (r.x * sc < keep) ? v.x * inv : 0.f;
+  v.y = (r.y * sc < keep) ? v.y * inv : 0.f;
+  v.z = (r.z * sc < keep) ? v.z * inv : 0.f;
+  v.w = (r.w * sc < keep) ? v.w * inv : 0.f;
+  reinterpret_cast<float4*>(x)[i] = v;
+}
+
+__global__ void __launch_bounds__(256) relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out,
+                                                       long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+}  // namespace
+
+int patchify(const float* img, float* out, int B, int Hi, int Wi, int ph, int pw, hipStream_t stream) {
+  DGVIT_CHECK_ARG(img && out && B > 0, "patchify: bad arguments");
+  DGVIT_CHECK_ARG(ph > 0 && pw > 0 && Hi % ph == 0 && Wi % pw == 0, "Image dimensions must be divisible by the patch size.");
+  const long long total = (long long)B * Hi * Wi;
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, img, out, B, Hi, Wi, ph, pw);
+  DGVIT_CHECK_LAUNCH("patchify");
+  return DGVIT_OK;
+}
+
+int goal_row(const float* goal, const float* pos, float* x0, int B, int N, int D, hipStream_t stream) {
+  DGVIT_CHECK_ARG(goal && pos && x0 && B > 0 && N > 0 && D > 0, "goal_row: bad arguments");
+  const long long total = (long long)B * D;
+  hipLaunchKernelGGL(goal_row_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, goal, pos, x0, B, N, D);
+  DGVIT_CHECK_LAUNCH("goal_row");
+  return DGVIT_OK;
+}
+
+int dropout_inplace(float* x, long long n, unsigned long long seed, float keep, hipStream_t stream) {
+  DGVIT_CHECK_ARG(x && n > 0 && n % 4 == 0 && keep > 0.f && keep <= 1.f, "dropout: bad arguments (n must be a multiple of 4)");
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, n4, seed, keep);
+  DGVIT_CHECK_LAUNCH("dropout");
+  return DGVIT_OK;
+}
+
+int relu_bwd(const float* dy, const float* y, float* out, long long n, hipStream_t stream) {
+  DGVIT_CHECK_ARG(dy && y && out && n > 0, "relu_bwd: bad arguments");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, y, out, n);
+  DGVIT_CHECK_LAUNCH("relu_bwd");
+  return DGVIT_OK;
+}

@@ -1,0 +1,254 @@
+// Row normalisations and column reductions of the DGViT encoder (HBM-bound; one wave64 per token row).
+//   LayerNorm  fwd/bwd : PreNorm's nn.LayerNorm, eps 1e-5 (GoalFormer.py:34,37)
+//   RMSNorm    fwd/bwd : F.normalize(x) * sqrt(D) * g, eps 1e-12 (GoalFormer.py:120-122)
+//   colsum             : bias gradients  db[n] = sum_t dY[t][n]
+// Column reductions (dgamma/dbeta/dg/db) are two-stage and deterministic: every workgroup writes one
+// partial row into a slab, reduce_slabs() adds the slabs in a fixed order.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- LayerNorm forward
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd, int T, int D,
+                                                            float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const float* xr = x + (long long)row * D;
+  float s = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    const float a = v.x - mu, b = v.y - mu, cc = v.z - mu, d = v.w - mu;
+    q += (a * a + b * b) + (cc * cc + d * d);
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+  float* yr = y + (long long)row * D;
+  for (int c = lane * 4; c < D; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 b = *reinterpret_cast<const float4*>(beta + c);
+    float4 o;
+    o.x = (v.x - mu) * rs * g.x + b.x;
+    o.y = (v.y - mu) * rs * g.y + b.y;
+    o.z = (v.z - mu) * rs * g.z + b.z;
+    o.w = (v.w - mu) * rs * g.w + b.w;
+    *reinterpret_cast<float4*>(yr + c) = o;
+  }
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+}
+
+// ---------------------------------------------------------------- LayerNorm backward
+// dx[t] = dres[t] + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+// partial[blk][0][c] = sum_rows dy * xhat (dgamma),  partial[blk][1][c] = sum_rows dy (dbeta)
+template <int NCH>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                            float* __restrict__ dx, float* __restrict__ partial, int T, int D) {
+  __shared__ float red[4][2][NCH * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 ag[NCH], ab[NCH], gm[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[i] = ag[i];
+    const int c = lane * 4 + i * 256;
+    gm[i] = c < D ? *reinterpret_cast<const float4*>(gamma + c) : ag[i];
+  }
+  const float invD = 1.f / (float)D;
+  for (int row = blockIdx.x * 4 + wave; row < T; row += gridDim.x * 4) {
+    const long long off = (long long)row * D;
+    const float mu = mean[row], rs = rstd[row];
+    float4 g[NCH], xh[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane * 4 + i * 256;
+      g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      xh[i] = g[i];
+      if (c < D) {
+        const float4 d = *reinterpret_cast<const float4*>(dy + off + c);
+        const float4 v = *reinterpret_cast<const float4*>(x + off + c);
+        xh[i] = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
+        ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+        g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
+        s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+      }
+    }
+    const float c1 = wave_sum(s1) * invD, c2 = wave_sum(s2) * invD;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = lane * 4 + i * 256;
+      if (c < D) {
+        float4 o;
+        o.x = rs * (g[i].x - c1 - xh[i].x * c2);
+        o.y = rs * (g[i].y - c1 - xh[i].y * c2);
+        o.z = rs * (g[i].z - c1 - xh[i].z * c2);
+        o.w = rs * (g[i].w - c1 - xh[i].w * c2);
+        if (dres) {
+          const float4 r = *reinterpret_cast<const float4*>(dres + off + c);
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        *reinterpret_cast<float4*>(dx + off + c) = o;
+      }
+    }
+  }
+  // block reduction of the per-wave column partials (fixed wave order -> deterministic)
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    *reinterpret_cast<float4*>(&red[wave][0][i * 256 + lane * 4]) = ag[i];
+    *reinterpret_cast<float4*>(&red[wave][1][i * 256 + lane * 4]) = ab[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * NCH * 256; c += 256) {
+    const int which = c / (NCH * 256), col = c % (NCH * 256);
+    if (col < D) {
+      const float s = ((red[0][which][col] + red[1][which][col]) + red[2][which][col]) + red[3][which][col];
+      partial[((long long)blockIdx.x * 2 + which) * D + col] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- RMSNorm (one wave per frame row)
+__global__ void __launch_bounds__(256) rmsnorm_fwd_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ g,
+                                                          float* __restrict__ y, int B, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* xr = x + row * ldx;
+  float q = 0.f;
+  for (int c = lane; c < D; c += 64) q += xr[c] * xr[c];
+  const float n = fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+  const float sc = sqrtf((float)D);
+  for (int c = lane; c < D; c += 64) y[(long long)row * D + c] = xr[c] / n * sc * g[c];
+}
+
+// dx = u/n - x * (u.x)/n^3 with u = dy*g*sqrt(D)  (second term dropped when the norm was clamped);
+// partial[blk][c] = sum_rows dy * x/n * sqrt(D)
+__global__ void __launch_bounds__(256) rmsnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, long long ldx,
+                                                          const float* __restrict__ g, float* __restrict__ dx, long long lddx,
+                                                          float* __restrict__ partial, int B, int D) {
+  extern __shared__ float red[];  // [4][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float sc = sqrtf((float)D);
+  for (int c = lane; c < D; c += 64) red[wave * D + c] = 0.f;
+  for (int row = blockIdx.x * 4 + wave; row < B; row += gridDim.x * 4) {
+    const float* xr = x + row * ldx;
+    const float* dr = dy + (long long)row * D;
+    float q = 0.f, ux = 0.f;
+    for (int c = lane; c < D; c += 64) {
+      const float xv = xr[c];
+      q += xv * xv;
+      ux += dr[c] * g[c] * sc * xv;
+    }
+    q = wave_sum(q);
+    ux = wave_sum(ux);
+    const float nr = sqrtf(q);
+    const bool clamped = nr < 1e-12f;
+    const float n = clamped ? 1e-12f : nr;
+    const float k = clamped ? 0.f : ux / (n * n * n);
+    for (int c = lane; c < D; c += 64) {
+      const float xv = xr[c], dv = dr[c];
+      dx[row * lddx + c] = dv * g[c] * sc / n - xv * k;
+      red[wave * D + c] += dv * xv / n * sc;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256)
+    partial[(long long)blockIdx.x * D + c] = ((red[c] + red[D + c]) + red[2 * D + c]) + red[3 * D + c];
+}
+
+// ---------------------------------------------------------------- column sums
+// grid (ceil(N/64), RB); block 256 = 64 columns x 4 row lanes; partial[rb][n]
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ a, long long lda, float* __restrict__ partial, int T,
+                                                     int N, int rgrp) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  float s = 0.f;
+  if (n < N) {
+    for (int t = blockIdx.y * 4 + ty; t < T; t += gridDim.y * 4) {
+      const long long pr = rgrp > 0 ? (long long)t + t / rgrp + 1 : (long long)t;
+      s += a[pr * lda + n];
+    }
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < N) partial[(long long)blockIdx.y * N + n] = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+}
+
+}  // namespace
+
+int layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int T, int D,
+                  float eps, hipStream_t stream) {
+  DGVIT_CHECK_ARG(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+  DGVIT_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0, "layernorm_fwd: D=%d must be a positive multiple of 4", D);
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, T, D, eps);
+  DGVIT_CHECK_LAUNCH("layernorm_fwd");
+  return DGVIT_OK;
+}
+
+int layernorm_bwd_blocks(int T) { return T < 2048 ? (T + 3) / 4 : 512; }
+
+// partial must hold layernorm_bwd_blocks(T) * 2 * D floats; dgamma/dbeta are written (not accumulated)
+int layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                  float* dx, float* dgamma, float* dbeta, float* partial, int T, int D, hipStream_t stream) {
+  DGVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && partial, "layernorm_bwd: null pointer");
+  DGVIT_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bwd: D=%d must be a multiple of 4, <= 1024", D);
+  const int nb = layernorm_bwd_blocks(T);
+  const int nch = (D + 255) / 256;
+#define LNB(NCH)                                                                                                              \
+  hipLaunchKernelGGL(layernorm_bwd_kernel<NCH>, dim3(nb), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dres, dx, partial, T, D)
+  if (nch == 1) LNB(1);
+  else if (nch == 2) LNB(2);
+  else if (nch == 3) LNB(3);
+  else LNB(4);
+#undef LNB
+  DGVIT_CHECK_LAUNCH("layernorm_bwd");
+  // partial is [nb][2][D]: reduce both halves with one pass each (stride 2*D)
+  int rc = reduce_slabs(partial, dgamma, D, nb, 2ll * D, stream);
+  if (rc) return rc;
+  return reduce_slabs(partial + D, dbeta, D, nb, 2ll * D, stream);
+}
+
+int rmsnorm_fwd(const float* x, long long ldx, const float* g, float* y, int B, int D, hipStream_t stream) {
+  DGVIT_CHECK_ARG(x && g && y && B > 0 && D > 0, "rmsnorm_fwd: bad arguments");
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, x, ldx, g, y, B, D);
+  DGVIT_CHECK_LAUNCH("rmsnorm_fwd");
+  return DGVIT_OK;
+}
+
+int rmsnorm_bwd_blocks(int B) { return B < 256 ? (B + 3) / 4 : 64; }
+
+int rmsnorm_bwd(const float* dy, const float* x, long long ldx, const float* g, float* dx, long long lddx, float* dg,
+                float* partial, int B, int D, hipStream_t stream) {
+  DGVIT_CHECK_ARG(dy && x && g && dx && dg && partial && B > 0 && D > 0 && D <= 4096, "rmsnorm_bwd: bad arguments");
+  const int nb = rmsnorm_bwd_blocks(B);
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), 4 * D * sizeof(float), stream, dy, x, ldx, g, dx, lddx, partial, B, D);
+  DGVIT_CHECK_LAUNCH("rmsnorm_bwd");
+  return reduce_slabs(partial, dg, D, nb, D, stream);
+}
+
+int colsum_blocks(int T) { return T < 1024 ? 1 : (T < 16384 ? 16 : 64); }
+
+// out[n] = sum_t a[row(t)][n]; partial must hold colsum_blocks(T) * N floats
+int colsum(const float* a, long long lda, float* out, float* partial, int T, int N, int rgrp, hipStream_t stream) {
+  DGVIT_CHECK_ARG(a && out && partial && T > 0 && N > 0, "colsum: bad arguments");
+  const int rb = colsum_blocks(T);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, rb), dim3(256), 0, stream, a, lda, partial, T, N, rgrp);
+  DGVIT_CHECK_LAUNCH("colsum");
+  return reduce_slabs(partial, out, N, rb, N, stream);
+}

@@ -1,0 +1,236 @@
+"""Autograd wrappers around the C ABI (include/dgvit_hip.h).
+
+``got_encoder`` is the whole of GoT.forward (reference GoalFormer.py:156-171) as ONE autograd node whose
+forward and backward are each one call into libdgvit_hip.so; ``linear`` is an nn.Linear (+ReLU) of the
+SAC heads (got_sac_network.py:111-121, 226-234).  The ``op_*`` helpers expose single operators for
+operator-level parity tests.  Tensors must be fp32 on a ROCm device; anything else raises.
+"""
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import DgvitError, dgvit_config
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise DgvitError(f"{name}: tensor is on {t.device}; the DGViT HIP path needs a ROCm device (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise DgvitError(f"{name}: dtype {t.dtype} unsupported, fp32 only")
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _table(tensors: Sequence[torch.Tensor]):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def make_config(image, patch, dim, depth, heads, dim_head, mlp_dim) -> dgvit_config:
+    return dgvit_config(int(image[0]), int(image[1]), int(patch[0]), int(patch[1]), int(dim), int(depth), int(heads),
+                        int(dim_head), int(mlp_dim))
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+class _GoTEncoder(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, goal, cfg_tuple, keep, seed, need_grad, *params):
+        lib = _lib.load()
+        cfg = dgvit_config(*cfg_tuple)
+        img, goal = _dev(img, "img"), _dev(goal, "goal")
+        params = [_dev(p, f"param[{i}]") for i, p in enumerate(params)]
+        nparam = _lib.NUM_GLOBAL_PARAMS + _lib.PARAMS_PER_LAYER * cfg.depth
+        if len(params) != nparam:
+            raise DgvitError(f"expected {nparam} parameter tensors, got {len(params)}")
+        if img.dim() != 3 or img.shape[1] != cfg.image_h or img.shape[2] != cfg.image_w:
+            raise DgvitError(f"img must be (B, {cfg.image_h}, {cfg.image_w}), got {tuple(img.shape)}")
+        B = img.shape[0]
+        if goal.shape != (B, cfg.dim):
+            raise DgvitError(f"goal must be ({B}, {cfg.dim}), got {tuple(goal.shape)}")
+        nws = lib.dgvit_got_workspace_floats(ctypes.byref(cfg), B, int(need_grad))
+        if nws < 0:
+            _lib.check(-1, "dgvit_got_workspace_floats")
+        ws = torch.empty(nws, dtype=torch.float32, device=img.device)
+        feat = torch.empty(B, cfg.dim, dtype=torch.float32, device=img.device)
+        with torch.cuda.device(img.device):
+            rc = lib.dgvit_got_forward(ctypes.byref(cfg), _table(params), _ptr(img), _ptr(goal), _ptr(feat), _ptr(ws), nws, B,
+                                       int(need_grad), float(keep), int(seed), _stream())
+        _lib.check(rc, "dgvit_got_forward")
+        if need_grad:
+            ctx.cfg_tuple, ctx.keep, ctx.seed, ctx.batch = cfg_tuple, float(keep), int(seed), B
+            ctx.ws = ws
+            ctx.save_for_backward(*params)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        lib = _lib.load()
+        cfg = dgvit_config(*ctx.cfg_tuple)
+        params = list(ctx.saved_tensors)
+        dfeat = _dev(dfeat, "dfeat")
+        B = ctx.batch
+        dev = dfeat.device
+        grads = [torch.empty_like(p) for p in params]
+        dgoal = torch.empty(B, cfg.dim, dtype=torch.float32, device=dev)
+        nsc = lib.dgvit_got_backward_scratch_floats(ctypes.byref(cfg), B)
+        scratch = torch.empty(nsc, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.dgvit_got_backward(ctypes.byref(cfg), _table(params), _table(grads), _ptr(dfeat), _ptr(dgoal), _ptr(ctx.ws),
+                                        ctx.ws.numel(), _ptr(scratch), nsc, B, ctx.keep, ctx.seed, _stream())
+        _lib.check(rc, "dgvit_got_backward")
+        ctx.ws = None
+        return (None, dgoal, None, None, None, None, *grads)
+
+
+def got_encoder(img, goal, cfg_tuple, params, dropout_keep=1.0, dropout_seed=0):
+    """feat (B, D) = GoT.forward(img (B,H,W), goal (B,D)); params in the table order of dgvit_hip.h."""
+    need_grad = torch.is_grad_enabled() and (goal.requires_grad or any(p.requires_grad for p in params))
+    return _GoTEncoder.apply(img, goal, tuple(cfg_tuple), dropout_keep, dropout_seed, need_grad, *params)
+
+
+# ------------------------------------------------------------------------------------------------ head Linear
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        lib = _lib.load()
+        x, w = _dev(x, "x"), _dev(w, "weight")
+        b = None if b is None else _dev(b, "bias")
+        if x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1]:
+            raise DgvitError(f"linear: x {tuple(x.shape)} does not match weight {tuple(w.shape)}")
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.dgvit_linear_forward(_ptr(x), _ptr(w), _ptr(b), _ptr(y), M, N, K, int(act), _stream())
+        _lib.check(rc, "dgvit_linear_forward")
+        ctx.act, ctx.has_bias = int(act), b is not None
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w, y = ctx.saved_tensors
+        dy = _dev(dy, "dy")
+        M, K = x.shape
+        N = w.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        nsc = lib.dgvit_linear_backward_scratch_floats(M, N, K)
+        scratch = torch.empty(nsc, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.dgvit_linear_backward(_ptr(dy), _ptr(x), _ptr(w), _ptr(y), _ptr(dx), _ptr(dw), _ptr(db), _ptr(scratch), nsc,
+                                           M, N, K, ctx.act, _stream())
+        _lib.check(rc, "dgvit_linear_backward")
+        return dx, dw, db, None
+
+
+def linear(x, weight, bias=None, relu=False):
+    """y = x W^T + b, optionally ReLU'd, on the MFMA GEMM."""
+    return _Linear.apply(x, weight, bias, 1 if relu else 0)
+
+
+# ------------------------------------------------------------------------------------------------ operator-level helpers
+def op_gemm(layout, epilogue, A, B, M, N, K, bias=None, res=None, aux=None, want_c2=False):
+    lib = _lib.load()
+    A, B = _dev(A, "A"), _dev(B, "B")
+    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    C2 = torch.empty_like(C) if want_c2 else None
+    nsc = lib.dgvit_gemm_scratch_floats(layout, M, N, K)
+    scratch = torch.empty(max(nsc, 4), dtype=torch.float32, device=A.device)
+    lda, ldb = A.shape[1], B.shape[1]
+    rc = lib.dgvit_gemm(layout, epilogue, _ptr(A), lda, _ptr(B), ldb, _ptr(C), N, M, N, K, _ptr(bias), _ptr(res), N, _ptr(C2), N,
+                        _ptr(aux), N, _ptr(scratch), scratch.numel(), _stream())
+    _lib.check(rc, "dgvit_gemm")
+    return (C, C2) if want_c2 else C
+
+
+def op_layernorm_fwd(x, gamma, beta):
+    lib = _lib.load()
+    x = _dev(x, "x")
+    T, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(T, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    _lib.check(lib.dgvit_layernorm_forward(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), T, D, _stream()),
+               "dgvit_layernorm_forward")
+    return y, mean, rstd
+
+
+def op_layernorm_bwd(dy, x, mean, rstd, gamma, dres=None):
+    lib = _lib.load()
+    T, D = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(D, dtype=torch.float32, device=x.device)
+    db = torch.empty_like(dg)
+    nsc = lib.dgvit_layernorm_backward_scratch_floats(T, D)
+    sc = torch.empty(nsc, dtype=torch.float32, device=x.device)
+    _lib.check(lib.dgvit_layernorm_backward(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dres), _ptr(dx), _ptr(dg),
+                                            _ptr(db), _ptr(sc), nsc, T, D, _stream()), "dgvit_layernorm_backward")
+    return dx, dg, db
+
+
+def op_rmsnorm_fwd(x, g):
+    lib = _lib.load()
+    x = _dev(x, "x")
+    B, D = x.shape
+    y = torch.empty_like(x)
+    _lib.check(lib.dgvit_rmsnorm_forward(_ptr(x), D, _ptr(g), _ptr(y), B, D, _stream()), "dgvit_rmsnorm_forward")
+    return y
+
+
+def op_rmsnorm_bwd(dy, x, g):
+    lib = _lib.load()
+    B, D = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(D, dtype=torch.float32, device=x.device)
+    nsc = lib.dgvit_rmsnorm_backward_scratch_floats(B, D)
+    sc = torch.empty(nsc, dtype=torch.float32, device=x.device)
+    _lib.check(lib.dgvit_rmsnorm_backward(_ptr(dy), _ptr(x), D, _ptr(g), _ptr(dx), D, _ptr(dg), _ptr(sc), nsc, B, D, _stream()),
+               "dgvit_rmsnorm_backward")
+    return dx, dg
+
+
+def op_attention_fwd(qkv, heads, dim_head):
+    lib = _lib.load()
+    qkv = _dev(qkv, "qkv")
+    B, N, W = qkv.shape
+    assert W == 3 * heads * dim_head
+    out = torch.empty(B, N, heads * dim_head, dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.dgvit_attention_forward(_ptr(qkv), _ptr(out), B, N, heads, dim_head, _stream()), "dgvit_attention_forward")
+    return out
+
+
+def op_attention_bwd(qkv, out, dout, heads, dim_head):
+    lib = _lib.load()
+    B, N, _ = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    _lib.check(lib.dgvit_attention_backward(_ptr(qkv), _ptr(out), _ptr(_dev(dout, "dout")), _ptr(dqkv), B, N, heads, dim_head,
+                                            _stream()), "dgvit_attention_backward")
+    return dqkv
+
+
+def op_patchify(img, patch):
+    lib = _lib.load()
+    img = _dev(img, "img")
+    B, H, W = img.shape
+    out = torch.empty(B, (H // patch[0]) * (W // patch[1]), patch[0] * patch[1], dtype=torch.float32, device=img.device)
+    _lib.check(lib.dgvit_patchify(_ptr(img), _ptr(out), B, H, W, patch[0], patch[1], _stream()), "dgvit_patchify")
+    return out
+
+
+def op_dropout_(x, seed, keep):
+    lib = _lib.load()
+    _lib.check(lib.dgvit_dropout(_ptr(x), x.numel(), int(seed), float(keep), _stream()), "dgvit_dropout")
+    return x

@@ -1,0 +1,125 @@
+"""MI355X-native twin of the reference encoder module ``GoalFormer.py``.
+
+Same public class (``GoT``), constructor signature, attribute names and ``state_dict`` keys as the
+reference (GoalFormer.py:123-171), so checkpoints and callers (got_sac_network.py:79-88,176-185) carry
+over.  The sub-modules below are parameter containers only: ``GoT.forward`` hands all tensors to one
+fused HIP forward/backward (functional.got_encoder); none of them runs PyTorch math.
+
+Differences from the reference, on purpose:
+  * ``patch_size`` is honoured (the reference hard-wires 16x20 / Linear(320, dim), GoalFormer.py:137-139);
+    with patch_size=(16, 20) the parameter shapes are identical;
+  * ``pool`` must be 'cls' and transformer ``dropout`` 0 (the only values the reference's nets ever use).
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import functional as F_
+
+
+def pair(t):
+    return t if isinstance(t, tuple) else (t, t)
+
+
+class _Holder(nn.Module):
+    """A sub-module that only owns parameters; calling it is a bug (the fused path reads the tensors)."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError(f"{type(self).__name__} holds parameters for the fused DGViT HIP encoder and is not callable")
+
+
+class RMSNorm(_Holder):
+    def __init__(self, dim, unit_offset=False):
+        super().__init__()
+        if unit_offset:
+            raise NotImplementedError("unit_offset=True is never used by the reference (GoalFormer.py:111)")
+        self.scale = dim ** 0.5
+        self.g = nn.Parameter(torch.ones(dim))
+
+
+class Patchify(_Holder):
+    """Slot 0 of ``to_patch_embedding`` (einops Rearrange in the reference: no parameters)."""
+
+    def __init__(self, p1, p2):
+        super().__init__()
+        self.p1, self.p2 = p1, p2
+
+
+class Attention(_Holder):
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner = dim_head * heads
+        if heads == 1 and dim_head == dim:
+            raise NotImplementedError("heads == 1 with dim_head == dim drops to_out in the reference (GoalFormer.py:56); unsupported")
+        self.heads, self.scale = heads, dim_head ** -0.5
+        self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout))
+
+
+class FeedForward(_Holder):
+    def __init__(self, dim, hidden_dim, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout), nn.Linear(hidden_dim, dim),
+                                 nn.Dropout(dropout))
+
+
+class PreNorm(_Holder):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+
+class Transformer(_Holder):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            nn.ModuleList([PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout)),
+                           PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout))])
+            for _ in range(depth)])
+
+
+class GoT(nn.Module):
+    """Goal-guided ViT encoder: (B, H, W) depth frames + (B, dim) goal embedding -> (B, dim) features."""
+
+    def __init__(self, *, image_size, patch_size, num_classes, dim, depth, heads, mlp_dim, pool='cls', channels=3,
+                 dim_head=64, dropout=0., emb_dropout=0.1):
+        super().__init__()
+        image_height, image_width = pair(image_size)
+        patch_height, patch_width = pair(patch_size)
+        self.layer_norm = RMSNorm(dim)
+        assert image_height % patch_height == 0 and image_width % patch_width == 0, \
+            'Image dimensions must be divisible by the patch size.'
+        assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
+        if pool != 'cls':
+            raise NotImplementedError("pool='mean' is never used by the reference networks; only 'cls' is built")
+        if dropout != 0.:
+            raise NotImplementedError("transformer dropout must be 0 (the reference never sets it)")
+        num_patches = (image_height // patch_height) * (image_width // patch_width)
+        # `channels` is accepted and ignored exactly like the reference (frames are single-channel, 3-D input)
+        self.to_patch_embedding = nn.Sequential(Patchify(patch_height, patch_width),
+                                                nn.Linear(patch_height * patch_width, dim))
+        self.pos_embedding = nn.Parameter(torch.randn(1, num_patches + 1, dim))
+        self.cls_token = nn.Parameter(torch.randn(1, 1, dim))   # unused, kept for checkpoint compatibility
+        self.dropout = nn.Dropout(emb_dropout)
+        self.transformer = Transformer(dim, depth, heads, dim_head, mlp_dim, dropout)
+        self.pool = pool
+        self.to_latent = nn.Identity()
+        self.mlp_head = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, num_classes))  # unused, kept for checkpoints
+        self._cfg = (image_height, image_width, patch_height, patch_width, dim, depth, heads, dim_head, mlp_dim)
+
+    def param_table(self):
+        """Parameters in the order of include/dgvit_hip.h's table."""
+        t = [self.pos_embedding, self.to_patch_embedding[1].weight, self.to_patch_embedding[1].bias, self.layer_norm.g]
+        for attn, ff in self.transformer.layers:
+            t += [attn.norm.weight, attn.norm.bias, attn.fn.to_qkv.weight, attn.fn.to_out[0].weight, attn.fn.to_out[0].bias,
+                  ff.norm.weight, ff.norm.bias, ff.fn.net[0].weight, ff.fn.net[0].bias, ff.fn.net[3].weight, ff.fn.net[3].bias]
+        return t
+
+    def forward(self, img, goal):
+        keep, seed = 1.0, 0
+        if self.training and self.dropout.p > 0:
+            keep = 1.0 - self.dropout.p
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())   # CPU generator: follows torch.manual_seed, no device sync
+        return F_.got_encoder(img, goal, self._cfg, self.param_table(), keep, seed)

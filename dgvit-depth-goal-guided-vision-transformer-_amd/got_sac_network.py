@@ -1,0 +1,3 @@
+"""Drop-in name for the reference module: ``from dgvit_amd.got_sac_network import GoTPolicy, GoTQNetwork, ...``."""
+from .sac_networks import (GoTPolicy, GoTQNetwork, DeterministicGoTPolicy, weights_init_, set_seed,  # noqa: F401
+                           LOG_SIG_MAX, LOG_SIG_MIN, epsilon)

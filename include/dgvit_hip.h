@@ -1,0 +1,151 @@
+/* libdgvit_hip.so -- C ABI of the MI355X (gfx950) DGViT encoder hot path.
+ *
+ * The reference (REGRAGUIahmed/DGViT) has no FFI: its boundary is the Python nn.Module surface of
+ *   src/vis_nav/vis_nav/GoalFormer.py        (GoT, Transformer, Attention, FeedForward, PreNorm, RMSNorm)
+ *   src/vis_nav/vis_nav/got_sac_network.py   (GoTPolicy, GoTQNetwork, DeterministicGoTPolicy)
+ * This header is the lower boundary a Python (ctypes) or C++ host binds instead of the aten ops those
+ * modules call.  Each entry point names the reference lines it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to a caller-allocated, contiguous fp32 buffer (row-major);
+ *   - nothing allocates, frees or synchronises; all work is enqueued on `stream` (a hipStream_t passed
+ *     as void*, 0 = the null stream); callable from any host thread (autograd's backward thread too);
+ *   - return value 0 = success, negative = error; dgvit_last_error() gives the thread-local message;
+ *   - sizes are element counts unless a name says bytes.
+ */
+#ifndef DGVIT_HIP_H
+#define DGVIT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+#define DGVIT_ABI_VERSION 1
+
+/* error codes */
+#define DGVIT_OK 0
+#define DGVIT_ERR_ARG (-1)
+#define DGVIT_ERR_HIP (-2)
+#define DGVIT_ERR_ALIGN (-3)
+#define DGVIT_ERR_WORKSPACE (-4)
+
+int dgvit_abi_version(void);
+const char* dgvit_last_error(void);
+/* number of visible HIP devices (<0 on error); does not create a context */
+int dgvit_device_count(void);
+
+/* ----------------------------------------------------------------------------------------------
+ * Encoder shape = the GoT constructor arguments (GoalFormer.py:124-154).  patch_h/patch_w are honoured
+ * (the reference hard-wires 16x20, GoalFormer.py:137-139).  dim_head must be 64 (or 32); tokens
+ * N = (image_h/patch_h)*(image_w/patch_w) + 1 <= 224.
+ * -------------------------------------------------------------------------------------------- */
+typedef struct dgvit_config {
+  int image_h, image_w;
+  int patch_h, patch_w;
+  int dim;       /* D */
+  int depth;     /* L */
+  int heads;     /* H */
+  int dim_head;  /* dh, inner width I = H*dh */
+  int mlp_dim;   /* M */
+} dgvit_config;
+
+/* Parameter / gradient tables: arrays of DGVIT_NUM_GLOBAL_PARAMS + DGVIT_PARAMS_PER_LAYER*depth device
+ * pointers in this order (reference state_dict key in brackets, prefix "trans."):
+ *   0 pos_embedding (1,N,D)                         [pos_embedding]
+ *   1 patch weight (D, patch_h*patch_w)             [to_patch_embedding.1.weight]
+ *   2 patch bias (D)                                [to_patch_embedding.1.bias]
+ *   3 final RMSNorm gain (D)                        [layer_norm.g]
+ *   then for layer i (prefix transformer.layers.i.):
+ *   +0 LN1 weight (D) [0.norm.weight]   +1 LN1 bias (D) [0.norm.bias]
+ *   +2 to_qkv weight (3I, D) [0.fn.to_qkv.weight]
+ *   +3 to_out weight (D, I) [0.fn.to_out.0.weight]  +4 to_out bias (D) [0.fn.to_out.0.bias]
+ *   +5 LN2 weight (D) [1.norm.weight]   +6 LN2 bias (D) [1.norm.bias]
+ *   +7 MLP fc1 weight (M, D) [1.fn.net.0.weight]    +8 fc1 bias (M) [1.fn.net.0.bias]
+ *   +9 MLP fc2 weight (D, M) [1.fn.net.3.weight]    +10 fc2 bias (D) [1.fn.net.3.bias]
+ * cls_token and mlp_head.* never take part in the forward (GoalFormer.py:143,151-154) and are not passed. */
+#define DGVIT_NUM_GLOBAL_PARAMS 4
+#define DGVIT_PARAMS_PER_LAYER 11
+
+/* floats of activation workspace the forward needs for `batch` frames.
+ * save_for_backward != 0: every layer keeps its activations (input of dgvit_got_backward);
+ * == 0: layers reuse one set of buffers (inference). */
+long long dgvit_got_workspace_floats(const dgvit_config* cfg, int batch, int save_for_backward);
+/* floats of scratch dgvit_got_backward needs (gradient temporaries, split-K slabs, reduction partials) */
+long long dgvit_got_backward_scratch_floats(const dgvit_config* cfg, int batch);
+
+/* GoT.forward (GoalFormer.py:156-171) incl. Transformer/PreNorm/Attention/FeedForward/RMSNorm
+ * (GoalFormer.py:31-122).
+ *   img  (B, image_h, image_w)   goal (B, D)   ->   feat (B, D)
+ * dropout_keep < 1 applies train-mode nn.Dropout(emb_dropout) (GoalFormer.py:163) with a Philox mask
+ * derived from dropout_seed; pass 1.0f for eval mode. */
+int dgvit_got_forward(const dgvit_config* cfg, const float* const* params, const float* img, const float* goal,
+                      float* feat, float* workspace, long long workspace_floats, int batch, int save_for_backward,
+                      float dropout_keep, unsigned long long dropout_seed, void* stream);
+
+/* Gradient of dgvit_got_forward (what autograd derives for GoalFormer.py:156-171).
+ *   dfeat (B, D) -> grads[] (same table order as params, each written, not accumulated), dgoal (B, D).
+ * `workspace` is the buffer the matching forward (save_for_backward=1) filled; same dropout_keep/seed. */
+int dgvit_got_backward(const dgvit_config* cfg, const float* const* params, float* const* grads, const float* dfeat,
+                       float* dgoal, const float* workspace, long long workspace_floats, float* scratch,
+                       long long scratch_floats, int batch, float dropout_keep, unsigned long long dropout_seed,
+                       void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Head Linears (got_sac_network.py:111,115-121,226,230-234,429,433-435):  y = act(x W^T + b)
+ *   x (M, K), w (N, K), b (N) or NULL, y (M, N); act: 0 = identity, 1 = ReLU.
+ * -------------------------------------------------------------------------------------------- */
+int dgvit_linear_forward(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int act,
+                         void* stream);
+long long dgvit_linear_backward_scratch_floats(int M, int N, int K);
+/* dy (M,N) is the gradient of y; with act = 1 it is masked by (y > 0) first (y = the forward output).
+ * Writes dx (M,K) (NULL to skip), dw (N,K), db (N) (NULL to skip). */
+int dgvit_linear_backward(const float* dy, const float* x, const float* w, const float* y, float* dx, float* dw,
+                          float* db, float* scratch, long long scratch_floats, int M, int N, int K, int act,
+                          void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Per-operator entry points (used by the encoder above; exported for operator-level parity tests).
+ * -------------------------------------------------------------------------------------------- */
+/* generic GEMM C = op(A) op(B) (+ epilogue); layout 0 NT (A MxK, B NxK), 1 NN (A MxK, B KxN), 2 TN (A KxM, B KxN).
+ * epilogue 0: C = acc + bias + res;  1: C = acc + bias, C2 = gelu(C);  2: C = acc * gelu'(aux);
+ *          3: C = relu(acc + bias);  4: C = aux > 0 ? acc : 0.
+ * layout 2 runs split over K with `scratch` slabs (dgvit_gemm_scratch_floats) and then reduces into C. */
+long long dgvit_gemm_scratch_floats(int layout, int M, int N, int K);
+int dgvit_gemm(int layout, int epilogue, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
+               int N, int K, const float* bias, const float* res, int ldr, float* C2, int ldc2, const float* aux,
+               int ldaux, float* scratch, long long scratch_floats, void* stream);
+/* test/bench knob: force the GEMM workgroup tile (0 = automatic, 64, 128) */
+void dgvit_set_gemm_tile(int tile);
+
+/* nn.LayerNorm(D), eps 1e-5 (GoalFormer.py:34,37): y, and the per-row mean / rstd saved for backward */
+int dgvit_layernorm_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                            int rows, int D, void* stream);
+long long dgvit_layernorm_backward_scratch_floats(int rows, int D);
+/* dx = dres + dLN(dy) (dres may be NULL), dgamma, dbeta */
+int dgvit_layernorm_backward(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                             const float* dres, float* dx, float* dgamma, float* dbeta, float* scratch,
+                             long long scratch_floats, int rows, int D, void* stream);
+
+/* RMSNorm (GoalFormer.py:120-122) on `rows` vectors x[r*ldx .. +D) */
+int dgvit_rmsnorm_forward(const float* x, long long ldx, const float* g, float* y, int rows, int D, void* stream);
+long long dgvit_rmsnorm_backward_scratch_floats(int rows, int D);
+int dgvit_rmsnorm_backward(const float* dy, const float* x, long long ldx, const float* g, float* dx, long long lddx,
+                           float* dg, float* scratch, long long scratch_floats, int rows, int D, void* stream);
+
+/* Attention core (GoalFormer.py:73-81): qkv (B, N, 3*H*dh) -> out (B, N, H*dh); scale dh^-1/2 */
+int dgvit_attention_forward(const float* qkv, float* out, int B, int N, int H, int dh, void* stream);
+int dgvit_attention_backward(const float* qkv, const float* out, const float* dout, float* dqkv, int B, int N, int H,
+                             int dh, void* stream);
+
+/* 'b (h p1) (w p2) -> b (h w) (p1 p2)' (GoalFormer.py:138) */
+int dgvit_patchify(const float* img, float* patches, int B, int image_h, int image_w, int patch_h, int patch_w,
+                   void* stream);
+/* in-place dropout with the encoder's Philox stream (n multiple of 4) */
+int dgvit_dropout(float* x, long long n, unsigned long long seed, float keep, void* stream);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGVIT_HIP_H */

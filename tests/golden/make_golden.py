@@ -206,8 +206,8 @@ def case_det(name, cfg, batch, seed):
 
 def main():
     C = O.GoTConfig
-    # tiny, arbitrary dims (bare GoT; dim_head 16 so everything is small), full gradients
-    tiny = C(image=(16, 24), patch=(8, 8), dim=32, depth=2, heads=2, dim_head=16, mlp_dim=64)
+    # tiny, arbitrary dims (bare GoT; dim_head 32, the smallest the fused attention kernel takes), full gradients
+    tiny = C(image=(16, 24), patch=(8, 8), dim=32, depth=2, heads=2, dim_head=32, mlp_dim=64)
     case_got("got_tiny_eval", tiny, 3, 0, full_grads=True)
     case_got("got_tiny_mask", tiny, 3, 1, with_mask=True, full_grads=True)
     # patch sizes BASELINE leaves open for 84x84 (N = 50 / 37 / 145 / 197), small width
