@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""DGViT hot-path benchmark (contract: see the task statement / DESIGN.md "Measurement").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+Workload (BASELINE.json metric, config C3): per GPU a batch of 512 synthetic 84x84 depth frames + polar goals
+through DGViT-small (GoTPolicy: 84x84 @ 12x12 patches, 6 layers, 8 heads, d=256, MLP 2048), train mode,
+forward + backward of an actor loss on (mean, log_std) against random targets, gradient all-reduce over
+RCCL when N > 1, then an Adam step.  One "step" = one such pass over one batch; value = frames/s over all
+ranks.  Inputs are resident in HBM before the timed region.  fp32 throughout (v_mfma_f32_32x32x2_f32).
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 256 CUs @ 2.4 GHz
+IMAGE, PATCH, DIM, DEPTH, HEADS = (84, 84), (12, 12), 256, 6, 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="frames per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=64)
+    return ap.parse_args()
+
+
+def cpu_baseline(batch):
+    """The CPU oracle (same math as the reference's PyTorch-CPU path, pinned to it by tests/golden) on a
+    bounded sample: `batch` frames fwd+bwd, best of 3, all host cores."""
+    from oracle import dgvit_oracle as O
+    cfg = O.GoTConfig(image=IMAGE, patch=PATCH, dim=DIM, depth=DEPTH, heads=HEADS)
+    # a 1-GPU box shares its host: use the cores this process may run on, capped at the 16-core share
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    params = O.make_params(O.policy_param_spec(cfg), 3407)
+    for v in params.values():
+        v.requires_grad_(True)
+    img, pstate, _, _ = O.make_inputs(cfg, batch, 3407)
+    tm, tl = torch.randn(batch, 2), torch.randn(batch, 2)
+    mask = (torch.rand(batch, cfg.tokens, cfg.dim) < 0.9).float()
+    best = float("inf")
+    for i in range(4):
+        t0 = time.perf_counter()
+        mean, log_std = O.policy_forward(params, img, pstate, cfg, drop_mask=mask)
+        loss = ((mean - tm) ** 2).mean() + ((log_std - tl) ** 2).mean()
+        grads = torch.autograd.grad(loss, [v for v in params.values()], allow_unused=True)
+        dt = time.perf_counter() - t0
+        if i > 0:
+            best = min(best, dt)
+    return {"value": round(batch / best, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/dgvit_oracle.py policy fwd+bwd on {batch} of the 512 frames, train-mode mask, best of 3, "
+                      f"{torch.get_num_threads()} torch threads"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs a ROCm GPU", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import dgvit_amd
+    from dgvit_amd.parallel import GradSync
+    from dgvit_amd import _lib
+    from oracle import dgvit_oracle as O   # inputs + FLOP model + cpu_baseline only; never on the measured path
+    lib = dgvit_amd.load_library()
+
+    cfg = O.GoTConfig(image=IMAGE, patch=PATCH, dim=DIM, depth=DEPTH, heads=HEADS)
+    B = args.batch
+    torch.manual_seed(3407)                      # identical initial weights on every rank (config.yaml:7 SEED)
+    model = dgvit_amd.GoTPolicy(2, 2, DEPTH, HEADS, DIM, image_size=IMAGE, patch_size=PATCH).to(dev).train()
+    sync = GradSync([model])
+    sync.broadcast_parameters(0)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, foreach=True)
+    img, pstate, _, _ = (t.to(dev) for t in O.make_inputs(cfg, B, 3407 + rank))   # rank-local frames, resident in HBM
+    g = torch.Generator(device="cpu").manual_seed(rank)
+    tgt_mean, tgt_ls = torch.randn(B, 2, generator=g).to(dev), torch.randn(B, 2, generator=g).to(dev)
+    torch.manual_seed(1000 + rank)               # decorrelate dropout masks across ranks
+
+    def step():
+        sync.zero_grad()
+        mean, log_std = model([img, pstate])
+        loss = ((mean - tgt_mean) ** 2).mean() + ((log_std - tgt_ls) ** 2).mean()
+        loss.backward()
+        sync.sync()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    lib.dgvit_profile_start(4096)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    kinds = _lib.PROFILE_KINDS
+    ms = (ctypes.c_double * kinds)()
+    work = (ctypes.c_double * kinds)()
+    cnt = (ctypes.c_longlong * kinds)()
+    lib.dgvit_profile_stop(ms, work, cnt)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = tmax.item()
+    final_loss = loss.item()
+
+    if rank == 0:
+        frames = B * world * args.steps
+        fps = frames / dt
+        fwd = cfg.fwd_flops_per_frame()
+        gemm_tflops = (work[0] / 1e12) / (ms[0] / 1e3) if ms[0] > 0 else 0.0
+        out = {
+            "metric": "depth frames/sec through DGViT fwd+bwd, batch 512x84x84",
+            "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: GoTPolicy DGViT-small (84x84@12x12, L6 H8 D256 M2048, N=50 tokens) actor fwd+bwd, "
+                                   "train mode (emb dropout 0.1), MSE-to-random-target loss, grad all-reduce + Adam step",
+                       "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "gflop_per_frame_fwd_bwd": round(3 * fwd / 1e9, 4)},
+            "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(gemm_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "gemm_f32_kernel (all instantiations: NT fwd, NN dgrad, TN wgrad)",
+                         "launches_per_step": int(cnt[0] // max(1, args.steps)),
+                         "avg_launch_ms": round(ms[0] / max(1, cnt[0]), 5),
+                         "avg_launch_gflop": round(work[0] / max(1, cnt[0]) / 1e9, 4)},
+            "end_to_end": {"tflops": round(fps * 3 * fwd / 1e12, 2), "frac_of_peak": round(fps * 3 * fwd / 1e12 / world / PEAK_F32_MFMA_TFLOPS, 4),
+                           "gemm_ms_per_step": round(ms[0] / args.steps, 3), "attn_fwd_ms_per_step": round(ms[1] / args.steps, 3),
+                           "attn_bwd_ms_per_step": round(ms[2] / args.steps, 3), "final_loss": round(final_loss, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -293,7 +293,9 @@ int launch_fwd(const float* qkv, float* out, int B, int N, int H, float scale, h
     done = true;
   }
   const int nw = NKT < 4 ? NKT : 4;
+  const int slot = profile_begin(PROF_ATTN_FWD, 4.0 * B * H * (double)N * N * DH, stream);
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(64 * nw), lds, stream, qkv, out, N, H, scale);
+  profile_end(slot, stream);
   DGVIT_CHECK_LAUNCH("attention_fwd");
   return DGVIT_OK;
 }
@@ -310,7 +312,9 @@ int launch_bwd(const float* qkv, const float* o, const float* dout, float* dqkv,
     done = true;
   }
   const int nw = NKT < 4 ? NKT : 4;
+  const int slot = profile_begin(PROF_ATTN_BWD, 8.0 * B * H * (double)N * N * DH, stream);
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(64 * nw), lds, stream, qkv, o, dout, dqkv, N, H, scale);
+  profile_end(slot, stream);
   DGVIT_CHECK_LAUNCH("attention_bwd");
   return DGVIT_OK;
 }

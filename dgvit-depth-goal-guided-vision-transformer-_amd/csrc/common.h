@@ -57,6 +57,11 @@ struct GemmParams {
   long long slab_stride; // EPI_SPLITK: floats between consecutive z slabs
 };
 
+// live timing hooks (profile.hip); slot < 0 = not recording
+int profile_begin(int kind, double work, hipStream_t st);
+void profile_end(int slot, hipStream_t st);
+enum { PROF_GEMM = 0, PROF_ATTN_FWD = 1, PROF_ATTN_BWD = 2, PROF_OTHER = 3 };
+
 int gemm_f32(int layout, int epi, const GemmParams& p, int nsplit, hipStream_t stream);
 int reduce_slabs(const float* slabs, float* out, long long n, int nslab, long long slab_stride, hipStream_t stream);
 

@@ -255,7 +255,9 @@ int launch(const GemmParams& p, int nsplit, hipStream_t stream) {
   const long long tiles = (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   DGVIT_CHECK_ARG(tiles > 0 && tiles < (1ll << 31), "gemm: bad tile count %lld", tiles);
   dim3 grid((unsigned)tiles, 1, (unsigned)nsplit);
+  const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, stream);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+  profile_end(slot, stream);
   DGVIT_CHECK_LAUNCH("gemm_f32_kernel");
   return DGVIT_OK;
 }

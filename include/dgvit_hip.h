@@ -144,6 +144,15 @@ int dgvit_patchify(const float* img, float* patches, int B, int image_h, int ima
 /* in-place dropout with the encoder's Philox stream (n multiple of 4) */
 int dgvit_dropout(float* x, long long n, unsigned long long seed, float keep, void* stream);
 
+/* ----------------------------------------------------------------------------------------------
+ * Optional live kernel timing (HIP events on the launch stream around every kernel launch).
+ * kinds: 0 GEMM (work = 2*M*N*K FLOPs), 1 attention fwd, 2 attention bwd (work = algorithmic FLOPs),
+ *        3 normalisation / reductions / elementwise (work = 0).
+ * -------------------------------------------------------------------------------------------- */
+#define DGVIT_PROFILE_KINDS 4
+int dgvit_profile_start(int max_records);
+int dgvit_profile_stop(double* ms, double* work, long long* launches);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }
