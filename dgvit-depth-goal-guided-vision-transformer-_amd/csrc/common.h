@@ -46,7 +46,7 @@ struct GemmParams {
   int lda, ldb;
   int M, N, K;
   int kchunk;            // K range handled by one blockIdx.z (multiple of BK); == K when not split
-  int a_kgrp;            // TN only: physical A row = k + k / a_kgrp + 1 when a_kgrp > 0 (token rows of patch rows)
+  int a_kgrp;            // must be 0 (row gathers are done by the caller)
   float* C; int ldc;
   const float* bias;     // [N] or null
   const float* res; int ldr;  // residual [*][N] or null
@@ -55,6 +55,8 @@ struct GemmParams {
   const float* aux; int ldaux;  // EPI_DGELU / EPI_DRELU input
   int c_rgrp;            // > 0: physical C row = m + m / c_rgrp + 1
   long long slab_stride; // EPI_SPLITK: floats between consecutive z slabs
+  int colsum;            // EPI_SPLITK: also write sum_k A[k][m] at slab[z][M*N + m] (bias gradient)
+  int evec;              // set by gemm_f32: epilogue may use float4 global accesses
 };
 
 // live timing hooks (profile.hip); slot < 0 = not recording
@@ -64,6 +66,8 @@ enum { PROF_GEMM = 0, PROF_ATTN_FWD = 1, PROF_ATTN_BWD = 2, PROF_OTHER = 3 };
 
 int gemm_f32(int layout, int epi, const GemmParams& p, int nsplit, hipStream_t stream);
 int reduce_slabs(const float* slabs, float* out, long long n, int nslab, long long slab_stride, hipStream_t stream);
+int reduce_slabs2(const float* slabs, float* out1, long long n1, float* out2, long long n, int nslab, long long slab_stride,
+                  hipStream_t stream);
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

@@ -58,11 +58,11 @@ GemmParams gp(const float* A, int lda, const float* B, int ldb, float* C, int ld
   return p;
 }
 
-// split-K plan for weight gradients: enough workgroups to cover the chip a few times over
+// split-K plan for weight gradients: tiles x splits ~ 2 workgroups per CU (all co-resident, one balanced wave)
 int wgrad_splits(int M, int N, int K) {
-  const int bt = (M >= 128 && N >= 128) ? 128 : 64;
+  const int bt = (M >= 128 && N >= 128) ? 128 : 64;  // must mirror pick_tile's automatic TN choice
   const long long tiles = (long long)((M + bt - 1) / bt) * ((N + bt - 1) / bt);
-  long long s = (1024 + tiles - 1) / tiles;
+  long long s = 512 / tiles;
   const long long maxs = (K + 255) / 256;  // at least 8 k-tiles per split
   if (s > maxs) s = maxs;
   if (s > 256) s = 256;
@@ -70,22 +70,27 @@ int wgrad_splits(int M, int N, int K) {
   return (int)s;
 }
 
-long long wgrad_scratch(int M, int N, int K) { return (long long)wgrad_splits(M, N, K) * al4((long long)M * N); }
+long long wgrad_slab(int M, int N) { return al4((long long)M * N + M); }
+long long wgrad_scratch(int M, int N, int K) { return (long long)wgrad_splits(M, N, K) * wgrad_slab(M, N); }
 
-// dW (M x N) = A^T B with A (K x M, lda), B (K x N, ldb); a_kgrp remaps A's rows (see GemmParams)
-int wgrad(const float* A, int lda, const float* B, int ldb, float* dW, int M, int N, int K, int a_kgrp, float* scratch,
+// dW (M x N) = A^T B with A (K x M, lda), B (K x N, ldb); optional db (M) = column sums of A (fused in the kernel);
+int wgrad(const float* A, int lda, const float* B, int ldb, float* dW, float* db, int M, int N, int K, float* scratch,
           long long scratch_floats, hipStream_t st) {
   const int ns = wgrad_splits(M, N, K);
-  const long long slab = al4((long long)M * N);
+  const long long slab = wgrad_slab(M, N);
   if (scratch_floats < ns * slab) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "wgrad: scratch %lld < %lld floats", scratch_floats, ns * slab);
   GemmParams p = gp(A, lda, B, ldb, scratch, N, M, N, K);
-  p.a_kgrp = a_kgrp;
   const int kt = (K + 31) / 32;
   p.kchunk = ((kt + ns - 1) / ns) * 32;
   p.slab_stride = slab;
+  p.colsum = db ? 1 : 0;
   const int ns_eff = (K + p.kchunk - 1) / p.kchunk;
   TRY(gemm_f32(GEMM_TN, EPI_SPLITK, p, ns_eff, st));
-  return reduce_slabs(scratch, dW, (long long)M * N, ns_eff, slab, st);
+  const long long mn = (long long)M * N;
+  if (db && mn % 4 == 0) return reduce_slabs2(scratch, dW, mn, db, mn + M, ns_eff, slab, st);
+  TRY(reduce_slabs(scratch, dW, mn, ns_eff, slab, st));
+  if (db) return reduce_slabs(scratch + mn, db, M, ns_eff, slab, st);
+  return DGVIT_OK;
 }
 
 struct Dims {
@@ -311,29 +316,26 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
     const float* lb = ws + w.layer0 + w.layer_stride * i;
     const float* xin = i == 0 ? ws + w.x0 : ws + w.layer0 + w.layer_stride * (i - 1) + w.xout;
     // ---- feed-forward branch: xout = fc2(gelu(fc1(ln2))) + xmid
-    TRY(colsum(dx, d.D, lg[L_FC2B], part, T, d.D, 0, st));
-    TRY(wgrad(dx, d.D, lb + w.a1, d.M, lg[L_FC2W], d.D, d.M, T, 0, slabs, s.slabs_floats, st));
+    TRY(wgrad(dx, d.D, lb + w.a1, d.M, lg[L_FC2W], lg[L_FC2B], d.D, d.M, T, slabs, s.slabs_floats, st));
     {
       GemmParams p = gp(dx, d.D, lp[L_FC2W], d.M, dh1, d.M, T, d.M, d.D);
       p.aux = lb + w.h1; p.ldaux = d.M;
       TRY(gemm_f32(GEMM_NN, EPI_DGELU, p, 1, st));  // dh1 = (dx W2) * gelu'(h1)
     }
-    TRY(colsum(dh1, d.M, lg[L_FC1B], part, T, d.M, 0, st));
-    TRY(wgrad(dh1, d.M, lb + w.ln2, d.D, lg[L_FC1W], d.M, d.D, T, 0, slabs, s.slabs_floats, st));
+    TRY(wgrad(dh1, d.M, lb + w.ln2, d.D, lg[L_FC1W], lg[L_FC1B], d.M, d.D, T, slabs, s.slabs_floats, st));
     {
       GemmParams p = gp(dh1, d.M, lp[L_FC1W], d.D, dln, d.D, T, d.D, d.M);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dln2 = dh1 W1
     }
     TRY(layernorm_bwd(dln, lb + w.xmid, lb + w.mean2, lb + w.rstd2, lp[L_LN2W], dx, dx2, lg[L_LN2W], lg[L_LN2B], part, T, d.D, st));
     // ---- attention branch: xmid = to_out(attn(to_qkv(ln1))) + xin       (dx2 = d xmid)
-    TRY(colsum(dx2, d.D, lg[L_OUTB], part, T, d.D, 0, st));
-    TRY(wgrad(dx2, d.D, lb + w.ao, d.I, lg[L_OUTW], d.D, d.I, T, 0, slabs, s.slabs_floats, st));
+    TRY(wgrad(dx2, d.D, lb + w.ao, d.I, lg[L_OUTW], lg[L_OUTB], d.D, d.I, T, slabs, s.slabs_floats, st));
     {
       GemmParams p = gp(dx2, d.D, lp[L_OUTW], d.I, dao, d.I, T, d.I, d.D);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dao = dxmid Wo
     }
     TRY(attention_bwd(lb + w.qkv, lb + w.ao, dao, dqkv, d.B, d.N, d.H, d.dh, st));
-    TRY(wgrad(dqkv, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV], 3 * d.I, d.D, T, 0, slabs, s.slabs_floats, st));
+    TRY(wgrad(dqkv, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV], nullptr, 3 * d.I, d.D, T, slabs, s.slabs_floats, st));
     {
       GemmParams p = gp(dqkv, 3 * d.I, lp[L_QKV], d.D, dln, d.D, T, d.D, 3 * d.I);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dln1 = dqkv Wqkv
@@ -346,8 +348,10 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
     HIP_TRY(hipMemcpy2DAsync(dgoal, sizeof(float) * d.D, dx, sizeof(float) * d.N * d.D, sizeof(float) * d.D, d.B,
                              hipMemcpyDeviceToDevice, st));
   TRY(colsum(dx, (long long)d.N * d.D, grads[P_POS], part, d.B, d.N * d.D, 0, st));  // dpos = sum over frames
-  TRY(colsum(dx, d.D, grads[P_PB], part, d.B * d.P, d.D, d.P, st));
-  TRY(wgrad(dx, d.D, ws + w.patches, d.pd, grads[P_PW], d.D, d.pd, d.B * d.P, d.P, slabs, s.slabs_floats, st));
+  // patch rows of dx0 (token rows 1..P of every frame) packed densely, then dW_pe = dx_patch^T patches, db_pe = column sums
+  HIP_TRY(hipMemcpy2DAsync(dln, sizeof(float) * d.P * d.D, dx + d.D, sizeof(float) * d.N * d.D, sizeof(float) * d.P * d.D, d.B,
+                           hipMemcpyDeviceToDevice, st));
+  TRY(wgrad(dln, d.D, ws + w.patches, d.pd, grads[P_PW], grads[P_PB], d.D, d.pd, d.B * d.P, slabs, s.slabs_floats, st));
   return DGVIT_OK;
 }
 
@@ -383,8 +387,7 @@ extern "C" int dgvit_linear_backward(const float* dy, const float* x, const floa
     TRY(relu_bwd(dy, y, dpre, (long long)M * N, st));
     g = dpre;
   }
-  if (db) TRY(colsum(g, N, db, part, M, N, 0, st));
-  TRY(wgrad(g, N, x, K, dw, N, K, M, 0, slabs, wgrad_scratch(N, K, M), st));
+  TRY(wgrad(g, N, x, K, dw, db, N, K, M, slabs, wgrad_scratch(N, K, M), st));
   if (dx) {
     GemmParams p = gp(g, N, wt, K, dx, K, M, K, N);
     TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));
@@ -406,7 +409,7 @@ extern "C" int dgvit_gemm(int layout, int epilogue, const float* A, int lda, con
     DGVIT_CHECK_ARG(epilogue == EPI_STORE && !bias && !res, "gemm: layout TN supports the plain epilogue only");
     DGVIT_CHECK_ARG(ldc == N, "gemm: layout TN writes a dense C (ldc == N)");
     DGVIT_CHECK_ARG(scratch, "gemm: layout TN needs scratch");
-    return wgrad(A, lda, B, ldb, C, M, N, K, 0, scratch, scratch_floats, st);
+    return wgrad(A, lda, B, ldb, C, nullptr, M, N, K, scratch, scratch_floats, st);
   }
   DGVIT_CHECK_ARG(layout == GEMM_NT || layout == GEMM_NN, "gemm: bad layout %d", layout);
   DGVIT_CHECK_ARG(epilogue >= EPI_STORE && epilogue <= EPI_DRELU, "gemm: bad epilogue %d", epilogue);

@@ -17,6 +17,10 @@
 // Global->LDS staging is register-staged and double-buffered in LDS: tile t+1 is fetched to VGPRs
 // before the MFMAs of tile t issue and written to the other LDS buffer after them (one barrier per
 // k-tile).  Four waves (2x2) per workgroup, each owning a (BM/2)x(BN/2) block of 32x32 accumulators.
+// Epilogue: the accumulators (column on the lane, rows in registers) are transposed through the now idle
+// staging LDS so that every global access of the epilogue -- C, residual, GELU input/output -- is a
+// 16-byte-per-lane, 512-byte-per-row coalesced float4; bias / residual / GELU / GELU' / ReLU are applied
+// on the way out.  The weight-gradient form also sums its A tiles over k (= the bias gradient) for free.
 #include "common.h"
 
 namespace {
@@ -35,13 +39,72 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 
 // ---- global -> register tile fetch ---------------------------------------------------------------
 // KC: tile is R rows x BK k (k contiguous in memory).  MC: tile is BK k-rows x R (row index contiguous).
+// VEC == 4: 16-byte buffer loads through a per-workgroup resource descriptor; rows/columns/k outside the
+// matrix are dropped by the hardware range check (offset >= num_records reads 0), so the fetch is
+// branch-free and can be scheduled among the MFMAs.  VEC == 1: scalar loads with explicit predicates
+// (odd leading dimensions / unaligned bases; small head and odd-patch GEMMs only).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define DGVIT_OOB 0xFFFFFFF0u
+
 template <int R, int BK, bool KC, int VEC>
 struct Fetch {
   static constexpr int NV = R * BK / 4 / 256;  // float4 slots per thread
   static constexpr int PER_ROW = KC ? BK / 4 : R / 4;
 
+  // --- VEC == 4 ---------------------------------------------------------------------------------
+  struct Plan {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned off[NV];   // byte offset of slot i at the block's first k-tile
+    int kc[NV];         // KC: k offset of the slot inside a tile; MC: k row of the slot inside a tile
+    bool ok[NV];        // MC: column in range
+    unsigned kstep;     // bytes to advance per k-tile
+  };
+
+  __device__ static __forceinline__ void plan(Plan& pl, const float* base, int ld, int r0, int rmax, int kbeg, int ktotal,
+                                              int tid) {
+    // resource base = first element this workgroup can touch; num_records = bytes from there to the end of the matrix
+    long long first, last;
+    if (KC) {
+      first = (long long)r0 * ld + kbeg;
+      last = (long long)(rmax - 1) * ld + ktotal;       // one past the last valid element
+    } else {
+      first = (long long)kbeg * ld + r0;
+      last = (long long)(ktotal - 1) * ld + rmax;
+    }
+    long long bytes = (last - first) * 4;
+    if (bytes > 0x7FFFFFFFll) bytes = 0x7FFFFFFFll;
+    if (bytes < 0) bytes = 0;
+    pl.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + first), 0, (int)bytes, 0x00020000);
+    pl.kstep = KC ? BK * 4u : (unsigned)BK * (unsigned)ld * 4u;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * 256;
+      const int a = f / PER_ROW, c = (f % PER_ROW) * 4;
+      if (KC) {
+        pl.off[i] = ((unsigned)a * (unsigned)ld + (unsigned)c) * 4u;
+        pl.kc[i] = c;
+        pl.ok[i] = true;  // rows past rmax fall outside num_records
+      } else {
+        pl.off[i] = ((unsigned)a * (unsigned)ld + (unsigned)c) * 4u;
+        pl.kc[i] = a;
+        pl.ok[i] = r0 + c < rmax;
+      }
+    }
+  }
+
+  // fetch k-tile number `t` (k0 = kbeg + t*BK); klim = kend - kbeg
+  __device__ static __forceinline__ void run4(float4 (&reg)[NV], const Plan& pl, int t, int klim) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bool in = pl.ok[i] && (t * BK + pl.kc[i] < klim);
+      const unsigned o = in ? pl.off[i] + (unsigned)t * pl.kstep : DGVIT_OOB;
+      reg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(pl.rsrc, o, 0, 0));
+    }
+  }
+
+  // --- VEC == 1 ---------------------------------------------------------------------------------
   __device__ static __forceinline__ void run(float4 (&reg)[NV], const float* __restrict__ base, int ld, int r0,
-                                             int rmax, int k0, int kend, int tid, int kgrp) {
+                                             int rmax, int k0, int kend, int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = tid + i * 256;
@@ -51,28 +114,19 @@ struct Fetch {
         const int row = r0 + a, k = k0 + c;
         if (row < rmax) {
           const float* src = base + (long long)row * ld + k;
-          if (VEC == 4) {
-            if (k < kend) v = *reinterpret_cast<const float4*>(src);
-          } else {
-            if (k + 0 < kend) v.x = src[0];
-            if (k + 1 < kend) v.y = src[1];
-            if (k + 2 < kend) v.z = src[2];
-            if (k + 3 < kend) v.w = src[3];
-          }
+          if (k + 0 < kend) v.x = src[0];
+          if (k + 1 < kend) v.y = src[1];
+          if (k + 2 < kend) v.z = src[2];
+          if (k + 3 < kend) v.w = src[3];
         }
       } else {
         const int k = k0 + a, col = r0 + c;
         if (k < kend) {
-          const long long prow = kgrp > 0 ? (long long)k + k / kgrp + 1 : (long long)k;
-          const float* src = base + prow * ld + col;
-          if (VEC == 4) {
-            if (col < rmax) v = *reinterpret_cast<const float4*>(src);
-          } else {
-            if (col + 0 < rmax) v.x = src[0];
-            if (col + 1 < rmax) v.y = src[1];
-            if (col + 2 < rmax) v.z = src[2];
-            if (col + 3 < rmax) v.w = src[3];
-          }
+          const float* src = base + (long long)k * ld + col;
+          if (col + 0 < rmax) v.x = src[0];
+          if (col + 1 < rmax) v.y = src[1];
+          if (col + 2 < rmax) v.z = src[2];
+          if (col + 3 < rmax) v.w = src[3];
         }
       }
       reg[i] = v;
@@ -102,6 +156,40 @@ __device__ __forceinline__ void frag(float (&out)[4], const float* lds, int row,
     for (int s = 0; s < 4; ++s) out[s] = p[s * (R + 4)];
   }
 }
+
+// ---- instruction-order hints for the pipelined main loop -----------------------------------------------
+// One k-tile = NG k-groups of MF MFMAs.  The LDS writes of the next tile (NW ds_write_b128) and the fetch of
+// the tile after it (NW buffer loads) are spread one per MFMA over the first k-group; the fragments of
+// k-group g+1 are read while k-group g's MFMAs run.  (LLVM SchedGroupMask: MFMA 0x8, VMEM read 0x20,
+// DS read 0x100, DS write 0x200.)
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+constexpr int cdiv_c(int a, int b) { return (a + b - 1) / b; }
+// m-th of H MFMAs, each followed by its share of NI instructions of kind MASK
+template <int m, int H, int NI, int MASK>
+__device__ __forceinline__ void spread() {
+  if constexpr (m < H) {
+    SGB(0x8, 1);
+    constexpr int c = cdiv_c((m + 1) * NI, H) - cdiv_c(m * NI, H);
+    if constexpr (c > 0) SGB(MASK, c);
+    spread<m + 1, H, NI, MASK>();
+  }
+}
+template <int MF, int NW, int RPG, int NG>
+__device__ __forceinline__ void sched_pattern() {
+  static_assert(MF >= 2 && MF % 2 == 0, "sched_pattern: MFMAs per k-group");
+  SGB(0x100, RPG);                       // fragments of k-group 0
+  spread<0, MF / 2, NW, 0x200>();        // first half of k-group 0: LDS writes of the next tile
+  if constexpr (NG > 1) SGB(0x100, RPG); // fragments of k-group 1
+  spread<0, MF / 2, NW, 0x20>();         // second half: global fetch of the tile after next
+  if constexpr (NG > 1) { if constexpr (NG > 2) SGB(0x100, RPG); SGB(0x8, MF); }
+  if constexpr (NG > 2) { if constexpr (NG > 3) SGB(0x100, RPG); SGB(0x8, MF); }
+  if constexpr (NG > 3) { if constexpr (NG > 4) SGB(0x100, RPG); SGB(0x8, MF); }
+  if constexpr (NG > 4) { if constexpr (NG > 5) SGB(0x100, RPG); SGB(0x8, MF); }
+  if constexpr (NG > 5) { if constexpr (NG > 6) SGB(0x100, RPG); SGB(0x8, MF); }
+  if constexpr (NG > 6) { if constexpr (NG > 7) SGB(0x100, RPG); SGB(0x8, MF); }
+  if constexpr (NG > 7) { SGB(0x8, MF); }
+}
+#undef SGB
 
 template <class T, int LAYOUT, int VEC, int EPI>
 __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(const GemmParams p) {
@@ -136,105 +224,236 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[FA::NV], rb[FB::NV];
-  FA::run(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid, p.a_kgrp);
-  FB::run(rb, p.B, p.ldb, n0, p.N, kbeg, kend, tid, 0);
-  FA::stash(ra, smem, tid);
-  FB::stash(rb, smem + A_TILE, tid);
-  __syncthreads();
+  float bsum = 0.f;  // TN only: column sum of this block's A rows (bias gradient), threads < BM of n-tile 0
+  const bool do_colsum = EPI == EPI_SPLITK && p.colsum && n0 == 0 && tid < BM;
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const float* la = smem + (kt & 1) * STAGE;
-    const float* lb = la + A_TILE;
-    const bool more = kt + 1 < nk;
-    if (more) {
-      FA::run(ra, p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid, p.a_kgrp);
-      FB::run(rb, p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid, 0);
-    }
+  float4 ra[FA::NV], rb[FB::NV];
+  const int klim = kend - kbeg;
+
+  // LDS -> fragments of one 8-deep k-group; MFMAs of one k-group
+  auto load_frags = [&](float (&fa)[TM][4], float (&fb)[TN][4], const float* la, const float* lb, int g) {
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
-      float fa[TM][4], fb[TN][4];
+    for (int i = 0; i < TM; ++i) frag<BM, BK, AKC>(fa[i], la, wm * WM + i * 32 + li, g, h);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) frag<BM, BK, AKC>(fa[i], la, wm * WM + i * 32 + li, g, h);
+    for (int j = 0; j < TN; ++j) frag<BN, BK, BKC>(fb[j], lb, wn * WN + j * 32 + li, g, h);
+  };
+  auto do_mfma = [&](const float (&fa)[TM][4], const float (&fb)[TN][4]) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) frag<BN, BK, BKC>(fb[j], lb, wn * WN + j * 32 + li, g, h);
+    for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s4], fb[j][s4], acc[i][j], 0, 0, 0);
+  };
+  auto mma_group = [&](const float* la, const float* lb, int g) {
+    float fa[TM][4], fb[TN][4];
+    load_frags(fa, fb, la, lb, g);
+    do_mfma(fa, fb);
+  };
+
+  if (VEC == 4) {
+    // Software pipeline (2 LDS buffers, 1 register set, 1 barrier per k-tile):
+    //   iteration t:  LDS[t+1] <- registers (tile t+1, fetched during iteration t-1)
+    //                 registers <- global tile t+2         (in flight for a whole iteration)
+    //                 MFMAs on LDS[t]
+    // the fetch is branch-free (hardware range check), so loads, LDS writes and MFMAs share one basic block.
+    typename FA::Plan pa;
+    typename FB::Plan pb;
+    FA::plan(pa, p.A, p.lda, m0, p.M, kbeg, p.K, tid);
+    FB::plan(pb, p.B, p.ldb, n0, p.N, kbeg, p.K, tid);
+    FA::run4(ra, pa, 0, klim);
+    FB::run4(rb, pb, 0, klim);
+    FA::stash(ra, smem, tid);
+    FB::stash(rb, smem + A_TILE, tid);
+    FA::run4(ra, pa, 1, klim);
+    FB::run4(rb, pb, 1, klim);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const float* la = smem + (kt & 1) * STAGE;
+      const float* lb = la + A_TILE;
       float* wa = smem + ((kt + 1) & 1) * STAGE;
+      // program order = wanted issue order where LDS reads and writes may alias for the compiler:
+      // fragments of k-group 0, then the next tile's LDS writes, then the k-groups (each prefetching the next)
+      float fa[2][TM][4], fb[2][TN][4];
+      load_frags(fa[0], fb[0], la, lb, 0);
       FA::stash(ra, wa, tid);
       FB::stash(rb, wa + A_TILE, tid);
+      FA::run4(ra, pa, kt + 2, klim);
+      FB::run4(rb, pb, kt + 2, klim);
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        if (g + 1 < BK / 8) load_frags(fa[(g + 1) & 1], fb[(g + 1) & 1], la, lb, g + 1);
+        do_mfma(fa[g & 1], fb[g & 1]);
+      }
+      sched_pattern<4 * TM * TN, FA::NV + FB::NV, (AKC ? TM : 4 * TM) + (BKC ? TN : 4 * TN), BK / 8>();
+      if (EPI == EPI_SPLITK && do_colsum) {
+#pragma unroll 8
+        for (int kk = 0; kk < BK; ++kk) bsum += la[kk * (BM + 4) + tid];
+      }
+      __syncthreads();
     }
+  } else {
+    FA::run(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
+    FB::run(rb, p.B, p.ldb, n0, p.N, kbeg, kend, tid);
+    FA::stash(ra, smem, tid);
+    FB::stash(rb, smem + A_TILE, tid);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const float* la = smem + (kt & 1) * STAGE;
+      const float* lb = la + A_TILE;
+      const bool more = kt + 1 < nk;
+      if (more) {
+        FA::run(ra, p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, kend, tid);
+        FB::run(rb, p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, kend, tid);
+      }
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) mma_group(la, lb, g);
+      if (EPI == EPI_SPLITK && do_colsum) {
+#pragma unroll 8
+        for (int kk = 0; kk < BK; ++kk) bsum += la[kk * (BM + 4) + tid];
+      }
+      if (more) {
+        float* wa = smem + ((kt + 1) & 1) * STAGE;
+        FA::stash(ra, wa, tid);
+        FB::stash(rb, wa + A_TILE, tid);
+      }
+      __syncthreads();
+    }
   }
 
-  // ---- epilogue: accumulator (col = lane&31, row = (r&3) + 8*(r>>2) + 4*h) -> global ---------------
+  // ---- epilogue ------------------------------------------------------------------------------------
   float* Cz = p.C;
-  if (EPI == EPI_SPLITK) Cz += (long long)blockIdx.z * p.slab_stride;
+  if (EPI == EPI_SPLITK) {
+    Cz += (long long)blockIdx.z * p.slab_stride;
+    if (p.colsum && n0 == 0 && tid < BM && m0 + tid < p.M) Cz[(long long)p.M * p.N + m0 + tid] = bsum;
+  }
+  // accumulator (col = lane&31, row = (r&3) + 8*(r>>2) + 4*h) -> LDS C image [rows][BN+4] -> float4 rows
+  constexpr int CS = BN + 4;
+  constexpr int NCHUNK = (BM * CS <= 2 * STAGE) ? 1 : 2;
+  constexpr int CROWS = BM / NCHUNK;
+  static_assert(CROWS * CS <= 2 * STAGE && (NCHUNK == 1 || CROWS == WM), "epilogue C image does not fit the staging LDS");
+  constexpr int C4 = BN / 4, RPP = 256 / C4;
+  const int cc = (tid % C4) * 4, rr0 = tid / C4;
+  const int n = n0 + cc;
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if ((EPI == EPI_STORE || EPI == EPI_GELU2 || EPI == EPI_RELU) && p.bias) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WN + j * 32 + li;
-    if (n >= p.N) continue;
-    float bias = 0.f;
-    if ((EPI == EPI_STORE || EPI == EPI_GELU2 || EPI == EPI_RELU) && p.bias) bias = p.bias[n];
+    for (int e = 0; e < 4; ++e)
+      if (n + e < p.N) bias4[e] = p.bias[n + e];
+  }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+  for (int ch = 0; ch < NCHUNK; ++ch) {
+    if (NCHUNK == 1 || wm == ch) {
+      const int rbase = NCHUNK == 1 ? wm * WM : 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r];
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            smem[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * CS + wn * WN + j * 32 + li] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (n < p.N) {
+      for (int rr = rr0; rr < CROWS; rr += RPP) {
+        const int m = m0 + ch * CROWS + rr;
+        if (m >= p.M) break;
+        const float4 t = *reinterpret_cast<const float4*>(smem + rr * CS + cc);
+        float v[4] = {t.x, t.y, t.z, t.w};
+        float w2[4];
+        long long crow = m;
+        if (EPI == EPI_STORE && p.c_rgrp > 0) crow = (long long)m + m / p.c_rgrp + 1;
+        float* cptr = Cz + crow * p.ldc + n;
         if (EPI == EPI_STORE) {
-          v += bias;
           if (p.res) {
-            const long long rr = p.res_mod > 0 ? (long long)(m % p.res_mod) + 1 : (long long)m;
-            v += p.res[rr * p.ldr + n];
+            const long long rrow = p.res_mod > 0 ? (long long)(m % p.res_mod) + 1 : (long long)m;
+            const float* rp = p.res + rrow * p.ldr + n;
+            if (p.evec) {
+              const float4 q = *reinterpret_cast<const float4*>(rp);
+              v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) v[e] += rp[e];
+            }
           }
-          const long long cm = p.c_rgrp > 0 ? (long long)m + m / p.c_rgrp + 1 : (long long)m;
-          Cz[cm * p.ldc + n] = v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bias4[e];
         } else if (EPI == EPI_GELU2) {
-          v += bias;
-          Cz[(long long)m * p.ldc + n] = v;
-          p.C2[(long long)m * p.ldc2 + n] = gelu_erf(v);
-        } else if (EPI == EPI_DGELU) {
-          Cz[(long long)m * p.ldc + n] = v * gelu_erf_grad(p.aux[(long long)m * p.ldaux + n]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] += bias4[e];
+            w2[e] = gelu_erf(v[e]);
+          }
         } else if (EPI == EPI_RELU) {
-          Cz[(long long)m * p.ldc + n] = fmaxf(v + bias, 0.f);
-        } else if (EPI == EPI_DRELU) {
-          Cz[(long long)m * p.ldc + n] = p.aux[(long long)m * p.ldaux + n] > 0.f ? v : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
+        } else if (EPI == EPI_DGELU || EPI == EPI_DRELU) {
+          const float* ap = p.aux + (long long)m * p.ldaux + n;
+          float a4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.evec) {
+            const float4 q = *reinterpret_cast<const float4*>(ap);
+            a4[0] = q.x; a4[1] = q.y; a4[2] = q.z; a4[3] = q.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < p.N) a4[e] = ap[e];
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = EPI == EPI_DGELU ? v[e] * gelu_erf_grad(a4[e]) : (a4[e] > 0.f ? v[e] : 0.f);
+        }
+        if (p.evec) {
+          *reinterpret_cast<float4*>(cptr) = make_float4(v[0], v[1], v[2], v[3]);
+          if (EPI == EPI_GELU2) *reinterpret_cast<float4*>(p.C2 + (long long)m * p.ldc2 + n) = make_float4(w2[0], w2[1], w2[2], w2[3]);
         } else {
-          Cz[(long long)m * p.ldc + n] = v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) {
+              cptr[e] = v[e];
+              if (EPI == EPI_GELU2) p.C2[(long long)m * p.ldc2 + n + e] = w2[e];
+            }
         }
       }
     }
+    if (ch + 1 < NCHUNK) __syncthreads();
   }
 }
 
-__global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
-                                                           long long n4, int nslab, long long stride) {
+// out1[0..n1) , out2[0..n-n1)  <-  sum over slabs of slab[z][0..n)   (fixed order -> deterministic)
+__global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out1,
+                                                           float* __restrict__ out2, long long n4, long long n14, int nslab,
+                                                           long long stride) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
-  float4 s = reinterpret_cast<const float4*>(slabs)[i];
-  for (int z = 1; z < nslab; ++z) {
-    const float4 v = reinterpret_cast<const float4*>(slabs + z * stride)[i];
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  const float4* src = reinterpret_cast<const float4*>(slabs) + i;
+  const long long st4 = stride / 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int z = 0;
+  for (; z + 4 <= nslab; z += 4) {
+    const float4 a = src[(z + 0) * st4], b = src[(z + 1) * st4], c = src[(z + 2) * st4], d = src[(z + 3) * st4];
+    s.x += (a.x + b.x) + (c.x + d.x);
+    s.y += (a.y + b.y) + (c.y + d.y);
+    s.z += (a.z + b.z) + (c.z + d.z);
+    s.w += (a.w + b.w) + (c.w + d.w);
   }
-  reinterpret_cast<float4*>(out)[i] = s;
+  for (; z < nslab; ++z) {
+    const float4 a = src[z * st4];
+    s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+  }
+  if (i < n14) reinterpret_cast<float4*>(out1)[i] = s;
+  else reinterpret_cast<float4*>(out2)[i - n14] = s;
 }
 
-__global__ void __launch_bounds__(256) reduce_slabs_scalar_kernel(const float* __restrict__ slabs, float* __restrict__ out,
-                                                                  long long n, int nslab, long long stride) {
+__global__ void __launch_bounds__(256) reduce_slabs_scalar_kernel(const float* __restrict__ slabs, float* __restrict__ out1,
+                                                                  float* __restrict__ out2, long long n, long long n1, int nslab,
+                                                                  long long stride) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float s = slabs[i];
-  for (int z = 1; z < nslab; ++z) s += slabs[z * stride + i];
-  out[i] = s;
+  float s = 0.f;
+  for (int z = 0; z < nslab; ++z) s += slabs[z * stride + i];
+  if (i < n1) out1[i] = s;
+  else out2[i - n1] = s;
 }
 
 template <class T, int LAYOUT, int VEC, int EPI>
@@ -262,16 +481,27 @@ int launch(const GemmParams& p, int nsplit, hipStream_t stream) {
   return DGVIT_OK;
 }
 
-using T128 = TileCfg<128, 128, 32>;
-using T64 = TileCfg<64, 64, 32>;
+// tile_hint = BM*1000000 + BN*1000 + BK (e.g. 128128032), 0 = automatic
+#define DGVIT_TILES(X) X(128, 128, 32) X(128, 128, 16) X(64, 64, 32) X(64, 64, 64) X(128, 64, 32) X(64, 128, 32) X(128, 64, 16) X(64, 128, 16)
 
 template <int LAYOUT, int EPI>
 int pick_tile(const GemmParams& p, int nsplit, bool vec4, int tile_hint, hipStream_t stream) {
-  if (!vec4) return launch<T64, LAYOUT, 1, EPI>(p, nsplit, stream);
-  bool big = p.M >= 128 && p.N >= 128;
-  if (tile_hint == 64) big = false;
-  if (tile_hint == 128) big = true;
-  return big ? launch<T128, LAYOUT, 4, EPI>(p, nsplit, stream) : launch<T64, LAYOUT, 4, EPI>(p, nsplit, stream);
+  if (!vec4) return launch<TileCfg<64, 64, 32>, LAYOUT, 1, EPI>(p, nsplit, stream);
+  int choice = tile_hint;
+  if (choice == 64) choice = 64064032;
+  if (choice == 128) choice = 128128032;
+  if (choice == 0) {
+    // measured on MI355X at T = 25600 token rows (tools/gemm_shapes_bench.py, profiles/r01_b_gemm_tiles.txt):
+    // weight gradients (long K, split over tokens) like the 128x128 tile; forward / data-gradient GEMMs are
+    // tile-quantisation and prologue bound, so they take small tiles: wide outputs 64x128x16, narrow 64x64x32
+    if (LAYOUT == GEMM_TN) choice = (p.M >= 128 && p.N >= 128) ? 128128032 : 64064032;
+    else choice = p.N >= 1024 ? 64128016 : 64064032;
+  }
+#define X(BM_, BN_, BK_) \
+  if (choice == BM_ * 1000000 + BN_ * 1000 + BK_) return launch<TileCfg<BM_, BN_, BK_>, LAYOUT, 4, EPI>(p, nsplit, stream);
+  DGVIT_TILES(X)
+#undef X
+  return dgvit_set_error(DGVIT_ERR_ARG, "gemm: unknown tile %d", choice);
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -291,9 +521,17 @@ int gemm_f32(int layout, int epi, const GemmParams& p, int nsplit, hipStream_t s
   if (layout == GEMM_NT) vec4 = vec4 && p.K % 4 == 0;
   if (layout == GEMM_NN) vec4 = vec4 && p.K % 4 == 0 && p.N % 4 == 0;
   if (layout == GEMM_TN) vec4 = vec4 && p.M % 4 == 0 && p.N % 4 == 0;
+  DGVIT_CHECK_ARG(p.a_kgrp == 0, "gemm: a_kgrp is no longer supported (gather the rows first)");
+  DGVIT_CHECK_ARG((long long)p.lda * 512 < 0x7FFFFFFFll && (long long)p.ldb * 512 < 0x7FFFFFFFll, "gemm: leading dimension too large");
+  DGVIT_CHECK_ARG(layout == GEMM_NT || (long long)p.kchunk * p.ldb * 4 < 0x7FFFFFFFll, "gemm: k-chunk x ldb exceeds the 2 GiB descriptor window");
+  DGVIT_CHECK_ARG(layout != GEMM_TN || (long long)p.kchunk * p.lda * 4 < 0x7FFFFFFFll, "gemm: k-chunk x lda exceeds the 2 GiB descriptor window");
+  GemmParams q = p;
+  q.evec = p.N % 4 == 0 && p.ldc % 4 == 0 && al16(p.C) && (!p.res || (p.ldr % 4 == 0 && al16(p.res))) &&
+           (!p.C2 || (p.ldc2 % 4 == 0 && al16(p.C2))) && (!p.aux || (p.ldaux % 4 == 0 && al16(p.aux))) &&
+           (epi != EPI_SPLITK || p.slab_stride % 4 == 0);
   const int th = g_gemm_tile_hint;
 #define CASE(L, E) \
-  if (layout == L && epi == E) return pick_tile<L, E>(p, nsplit, vec4, th, stream);
+  if (layout == L && epi == E) return pick_tile<L, E>(q, nsplit, vec4, th, stream);
   CASE(GEMM_NT, EPI_STORE)
   CASE(GEMM_NT, EPI_GELU2)
   CASE(GEMM_NT, EPI_RELU)
@@ -305,14 +543,24 @@ int gemm_f32(int layout, int epi, const GemmParams& p, int nsplit, hipStream_t s
   return dgvit_set_error(DGVIT_ERR_ARG, "gemm: unsupported layout/epilogue %d/%d", layout, epi);
 }
 
-int reduce_slabs(const float* slabs, float* out, long long n, int nslab, long long slab_stride, hipStream_t stream) {
-  DGVIT_CHECK_ARG(slabs && out && n > 0 && nslab >= 1, "reduce_slabs: bad arguments");
-  if (n % 4 == 0 && slab_stride % 4 == 0 && al16(slabs) && al16(out)) {
+// out1 gets the first n1 sums, out2 (may be null when n1 == n) the remaining n - n1
+int reduce_slabs2(const float* slabs, float* out1, long long n1, float* out2, long long n, int nslab, long long slab_stride,
+                  hipStream_t stream) {
+  DGVIT_CHECK_ARG(slabs && out1 && n > 0 && n1 > 0 && n1 <= n && nslab >= 1 && (n1 == n || out2), "reduce_slabs: bad arguments");
+  const int slot = profile_begin(PROF_OTHER, 0.0, stream);
+  if (n % 4 == 0 && n1 % 4 == 0 && slab_stride % 4 == 0 && al16(slabs) && al16(out1) && (n1 == n || al16(out2))) {
     const long long n4 = n / 4;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, slabs, out, n4, nslab, slab_stride);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, slabs, out1, out2, n4, n1 / 4,
+                       nslab, slab_stride);
   } else {
-    hipLaunchKernelGGL(reduce_slabs_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slabs, out, n, nslab, slab_stride);
+    hipLaunchKernelGGL(reduce_slabs_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slabs, out1, out2, n, n1,
+                       nslab, slab_stride);
   }
+  profile_end(slot, stream);
   DGVIT_CHECK_LAUNCH("reduce_slabs");
   return DGVIT_OK;
+}
+
+int reduce_slabs(const float* slabs, float* out, long long n, int nslab, long long slab_stride, hipStream_t stream) {
+  return reduce_slabs2(slabs, out, n, nullptr, n, nslab, slab_stride, stream);
 }

@@ -218,10 +218,8 @@ int layernorm_bwd(const float* dy, const float* x, const float* mean, const floa
   else LNB(4);
 #undef LNB
   DGVIT_CHECK_LAUNCH("layernorm_bwd");
-  // partial is [nb][2][D]: reduce both halves with one pass each (stride 2*D)
-  int rc = reduce_slabs(partial, dgamma, D, nb, 2ll * D, stream);
-  if (rc) return rc;
-  return reduce_slabs(partial + D, dbeta, D, nb, 2ll * D, stream);
+  // partial is [nb][2][D]: one pass reduces both halves (stride 2*D), first D sums -> dgamma, next D -> dbeta
+  return reduce_slabs2(partial, dgamma, D, dbeta, 2ll * D, nb, 2ll * D, stream);
 }
 
 int rmsnorm_fwd(const float* x, long long ldx, const float* g, float* y, int B, int D, hipStream_t stream) {
