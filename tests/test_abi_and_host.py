@@ -1,0 +1,123 @@
+"""CPU (no GPU): the C-ABI library loads and exports every symbol include/dgvit_hip.h declares, size queries and
+argument validation work without a device, and the host modules mirror the reference's nn.Module surface."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from helpers import O, ROOT
+
+HEADER = os.path.join(ROOT, "include", "dgvit_hip.h")
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import __graft_entry__
+    __graft_entry__.build()          # hipcc cross-compiles gfx950 without a GPU; no-op when up to date
+    import dgvit_amd
+    return dgvit_amd
+
+
+def _header_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(dgvit_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(n for n in names if n != "dgvit_config"))
+
+
+def test_library_exports_every_header_symbol(amd):
+    from dgvit_amd import _lib
+    lib = amd.load_library()
+    declared = _header_functions()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"libdgvit_hip.so does not export {name}"
+        assert name in _lib.SIGNATURES, f"ctypes binding has no signature for {name}"
+    assert sorted(_lib.SIGNATURES) == declared, "binding and header disagree"
+    assert lib.dgvit_abi_version() == 1
+
+
+def test_size_queries_and_validation_without_gpu(amd):
+    from dgvit_amd._lib import dgvit_config
+    lib = amd.load_library()
+    cfg = dgvit_config(84, 84, 12, 12, 256, 6, 8, 64, 2048)
+    train = lib.dgvit_got_workspace_floats(ctypes.byref(cfg), 512, 1)
+    infer = lib.dgvit_got_workspace_floats(ctypes.byref(cfg), 512, 0)
+    assert train > infer > 0
+    # per layer: ln1, xmid, ln2, xout (T*D each) + qkv (3I) + ao (I) + h1, a1 (M each) + 4 stat rows
+    T, D, I, M = 512 * 50, 256, 512, 2048
+    per_layer = T * (4 * D + 4 * I + 2 * M + 4)
+    assert train >= 6 * per_layer
+    assert lib.dgvit_got_backward_scratch_floats(ctypes.byref(cfg), 512) > T * M
+    # reference assertion text for indivisible images (GoalFormer.py:131)
+    bad = dgvit_config(84, 84, 16, 20, 256, 6, 8, 64, 2048)
+    assert lib.dgvit_got_workspace_floats(ctypes.byref(bad), 4, 1) < 0
+    assert b"divisible by the patch size" in lib.dgvit_last_error()
+    bad = dgvit_config(84, 84, 12, 12, 256, 6, 8, 48, 2048)
+    assert lib.dgvit_got_workspace_floats(ctypes.byref(bad), 4, 1) < 0
+    assert b"dim_head" in lib.dgvit_last_error()
+    bad = dgvit_config(224, 224, 8, 8, 256, 6, 8, 64, 2048)   # 785 tokens > fused-attention limit
+    assert lib.dgvit_got_workspace_floats(ctypes.byref(bad), 4, 1) < 0
+    assert lib.dgvit_linear_backward_scratch_floats(512, 128, 256) > 0
+    assert lib.dgvit_gemm_scratch_floats(2, 1536, 256, 25600) >= 1536 * 256
+    assert lib.dgvit_gemm_scratch_floats(0, 1536, 256, 25600) == 0
+
+
+def test_no_cpu_fallback(amd):
+    m = amd.GoTPolicy(2, 2, 1, 2, 64)
+    with pytest.raises(amd.DgvitError, match="no CPU fallback"):
+        m([torch.zeros(1, 128, 160), torch.zeros(1, 2)])
+    with pytest.raises(amd.DgvitError):
+        amd.functional.linear(torch.zeros(2, 4), torch.zeros(3, 4))
+    with pytest.raises(RuntimeError, match="not callable"):
+        m.trans.transformer(torch.zeros(1))
+
+
+@pytest.mark.parametrize("kind", ["policy", "qnet", "detpolicy"])
+def test_state_dict_abi_matches_reference_keys(amd, kind):
+    """Keys, order and shapes equal the reference's (pinned by make_golden.py's strict load into the reference)."""
+    cfg = O.GoTConfig(dim=64, depth=4, heads=4)
+    ctor = {"policy": amd.GoTPolicy, "qnet": amd.GoTQNetwork, "detpolicy": amd.DeterministicGoTPolicy}[kind]
+    spec = {"policy": O.policy_param_spec, "qnet": O.qnet_param_spec, "detpolicy": O.detpolicy_param_spec}[kind](cfg)
+    m = ctor(2, 2, cfg.depth, cfg.heads, cfg.dim)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == [(k, s) for k, s, _ in spec]
+    assert [k for k, _ in m.named_parameters()] == [k for k, _, _ in spec]
+    m.load_state_dict(O.make_params(spec, 0), strict=True)
+    # survives deepcopy / pickling / .to(), like DRL.py:169 and attention_imitating.py:199 need
+    import copy, io
+    m2 = copy.deepcopy(m)
+    buf = io.BytesIO()
+    torch.save(m2, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m3.state_dict().values()))
+    assert m.to("cpu") is m
+    for attr in ("trans", "fc_embed", "fc1", "fc2"):
+        assert hasattr(m, attr)
+
+
+def test_init_follows_reference(amd):
+    """Xavier-uniform(gain 1) on Linear weights (got_sac_network.py:30-33); RMSNorm gain 1; mean/log_std of the
+    deterministic policy are created after the Xavier pass and keep nn.Linear's default init (:410-413)."""
+    torch.manual_seed(0)
+    m = amd.GoTPolicy(2, 2, 2, 2, 64)
+    w = m.trans.transformer.layers[0][1].fn.net[0].weight
+    bound = (6.0 / (w.shape[0] + w.shape[1])) ** 0.5
+    assert w.abs().max().item() <= bound + 1e-6 and w.abs().max().item() > 0.9 * bound
+    assert torch.equal(m.trans.layer_norm.g, torch.ones(64))
+    d = amd.DeterministicGoTPolicy(2, 2, 1, 2, 64)
+    assert d.mean_linear.weight.abs().max().item() <= (1.0 / 32) ** 0.5 + 1e-6
+    assert m.trans.pos_embedding.shape == (1, 65, 64) and m.trans.cls_token.shape == (1, 1, 64)
+    m84 = amd.GoTPolicy(2, 2, 1, 2, 64, image_size=(84, 84), patch_size=(12, 12))
+    assert m84.trans.pos_embedding.shape == (1, 50, 64) and m84.trans.to_patch_embedding[1].weight.shape == (64, 144)
+    with pytest.raises(AssertionError, match="divisible by the patch size"):
+        amd.GoT(image_size=(84, 84), patch_size=(16, 20), num_classes=2, dim=64, depth=1, heads=2, mlp_dim=64)
+
+
+def test_drop_in_module_names(amd):
+    from dgvit_amd.GoalFormer import GoT
+    from dgvit_amd.got_sac_network import GoTPolicy, GoTQNetwork, DeterministicGoTPolicy, weights_init_
+    assert GoT is amd.GoT and GoTPolicy is amd.GoTPolicy and GoTQNetwork is amd.GoTQNetwork
+    assert DeterministicGoTPolicy is amd.DeterministicGoTPolicy and callable(weights_init_)
