@@ -72,7 +72,7 @@ __device__ __forceinline__ void store_T(const f32x16 (&o)[DH / 32], float* rowpt
 // ------------------------------------------------------------------------------------ forward
 template <int DH, int NKT>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int H,
-                                                       float scale) {
+                                                       float scale, int nq) {
   constexpr int SK = DH + 4, NP = NKT * 32, DT = DH / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;
@@ -88,10 +88,11 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
   stage_rows<DH, SK>(Vs, base + 2 * I, ld, N, NP, tid, blockDim.x);
   __syncthreads();
 
-  for (int qt = wave; qt < NKT; qt += nw) {
+  const int nqt = (nq + 31) / 32;   // only queries < nq are needed (nq = 1: the last block keeps token 0 only)
+  for (int qt = wave; qt < nqt; qt += nw) {
     const int q = qt * 32 + li;
     float4 qf[DH / 8];
-    row_frags<DH>(qf, base + q * ld, q < N, h, scale);
+    row_frags<DH>(qf, base + q * ld, q < nq, h, scale);
 
     f32x16 s[NKT];
 #pragma unroll
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[dt * 32], s[kt][r], o[dt], 0, 0, 0);
       }
-    if (q < N) store_T<DH>(o, out + ((long long)b * N + q) * I + hd * DH, h, 1.f / l);
+    if (q < nq) store_T<DH>(o, out + ((long long)b * N + q) * I + hd * DH, h, 1.f / l);
   }
 }
 
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 template <int DH, int NKT>
 __global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o_fwd,
                                                        const float* __restrict__ d_out, float* __restrict__ dqkv, int N, int H,
-                                                       float scale) {
+                                                       float scale, int nq) {
   constexpr int SK = DH + 4, NP = NKT * 32, DT = DH / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* X = smem;                 // phase 1: K      phase 2: Q
@@ -164,9 +165,10 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__
   __syncthreads();
 
   // ---- phase 1: one query tile per wave -> dQ, lse, delta
-  for (int qt = wave; qt < NKT; qt += nw) {
+  const int nqt = (nq + 31) / 32;
+  for (int qt = wave; qt < nqt; qt += nw) {
     const int q = qt * 32 + li;
-    const bool qv = q < N;
+    const bool qv = q < nq;
     float4 qf[DH / 8], dof[DH / 8], of[DH / 8];
     row_frags<DH>(qf, base + q * ld, qv, h, scale);
     row_frags<DH>(dof, dobase + (long long)q * I, qv, h, 1.f);
@@ -234,8 +236,8 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__
   __syncthreads();
 
   // ---- phase 2: Q and dO into LDS, one key tile per wave -> dK, dV
-  stage_rows<DH, SK>(X, base, ld, N, NP, tid, blockDim.x);
-  stage_rows<DH, SK>(Y, dobase, I, N, NP, tid, blockDim.x);
+  stage_rows<DH, SK>(X, base, ld, nq, NP, tid, blockDim.x);      // rows >= nq are zero-filled: they carry no gradient
+  stage_rows<DH, SK>(Y, dobase, I, nq, NP, tid, blockDim.x);
   __syncthreads();
   for (int kt = wave; kt < NKT; kt += nw) {
     const int key = kt * 32 + li;
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__
         dv[dt][r] = 0.f;
       }
 #pragma unroll 1
-    for (int qt = 0; qt < NKT; ++qt) {
+    for (int qt = 0; qt < nqt; ++qt) {
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -264,7 +266,7 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int q = qt * 32 + acc_row(r, h);
-        const float pv = (kv && q < N) ? expf(s[r] * scale - lse_s[q]) : 0.f;
+        const float pv = (kv && q < nq) ? expf(s[r] * scale - lse_s[q]) : 0.f;
         const float ds = pv * (dp[r] - del_s[q]) * scale;
         const float* dorow = Y + q * SK + li;
         const float* qrow = X + q * SK + li;
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__
 }
 
 template <int DH, int NKT>
-int launch_fwd(const float* qkv, float* out, int B, int N, int H, float scale, hipStream_t stream) {
+int launch_fwd(const float* qkv, float* out, int B, int N, int H, float scale, int nq, hipStream_t stream) {
   constexpr size_t lds = (size_t)2 * NKT * 32 * (DH + 4) * sizeof(float);
   auto kern = attn_fwd_kernel<DH, NKT>;
   static bool done = false;
@@ -293,15 +295,15 @@ int launch_fwd(const float* qkv, float* out, int B, int N, int H, float scale, h
     done = true;
   }
   const int nw = NKT < 4 ? NKT : 4;
-  const int slot = profile_begin(PROF_ATTN_FWD, 4.0 * B * H * (double)N * N * DH, stream);
-  hipLaunchKernelGGL(kern, dim3(B * H), dim3(64 * nw), lds, stream, qkv, out, N, H, scale);
+  const int slot = profile_begin(PROF_ATTN_FWD, 4.0 * B * H * (double)nq * N * DH, stream);
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(64 * nw), lds, stream, qkv, out, N, H, scale, nq);
   profile_end(slot, stream);
   DGVIT_CHECK_LAUNCH("attention_fwd");
   return DGVIT_OK;
 }
 
 template <int DH, int NKT>
-int launch_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, int B, int N, int H, float scale,
+int launch_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, int B, int N, int H, float scale, int nq,
                hipStream_t stream) {
   constexpr size_t lds = ((size_t)2 * NKT * 32 * (DH + 4) + 2 * NKT * 32) * sizeof(float);
   auto kern = attn_bwd_kernel<DH, NKT>;
@@ -312,8 +314,8 @@ int launch_bwd(const float* qkv, const float* o, const float* dout, float* dqkv,
     done = true;
   }
   const int nw = NKT < 4 ? NKT : 4;
-  const int slot = profile_begin(PROF_ATTN_BWD, 8.0 * B * H * (double)N * N * DH, stream);
-  hipLaunchKernelGGL(kern, dim3(B * H), dim3(64 * nw), lds, stream, qkv, o, dout, dqkv, N, H, scale);
+  const int slot = profile_begin(PROF_ATTN_BWD, 8.0 * B * H * (double)nq * N * DH, stream);
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(64 * nw), lds, stream, qkv, o, dout, dqkv, N, H, scale, nq);
   profile_end(slot, stream);
   DGVIT_CHECK_LAUNCH("attention_bwd");
   return DGVIT_OK;
@@ -336,22 +338,26 @@ int launch_bwd(const float* qkv, const float* o, const float* dout, float* dqkv,
   }
 
 // qkv (B, N, 3*H*dh) -> out (B, N, H*dh)
-int attention_fwd(const float* qkv, float* out, int B, int N, int H, int dh, hipStream_t stream) {
+// nq = number of leading query tokens whose output is needed (N normally)
+int attention_fwd(const float* qkv, float* out, int B, int N, int H, int dh, int nq, hipStream_t stream) {
   DGVIT_CHECK_ARG(qkv && out && B > 0 && N > 0 && H > 0, "attention_fwd: bad arguments");
   DGVIT_CHECK_ARG((long long)B * H < (1ll << 31), "attention_fwd: B*H too large");
   const int nkt = (N + 31) / 32;
   const float scale = 1.0f / sqrtf((float)dh);
-  ATTN_DISPATCH(launch_fwd, qkv, out, B, N, H, scale, stream)
+  DGVIT_CHECK_ARG(nq >= 1 && nq <= N, "attention_fwd: bad query count");
+  ATTN_DISPATCH(launch_fwd, qkv, out, B, N, H, scale, nq, stream)
   return dgvit_set_error(DGVIT_ERR_ARG, "attention_fwd: unsupported dim_head=%d / tokens=%d (dim_head 64 with N<=224, or 32 with N<=64)", dh, N);
 }
 
 // dqkv (B, N, 3*H*dh) is fully written for rows < N
-int attention_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, int B, int N, int H, int dh,
+// with nq < N only rows < nq of `o`/`dout` are read and only rows < nq of dq are written (dk, dv: all rows)
+int attention_bwd(const float* qkv, const float* o, const float* dout, float* dqkv, int B, int N, int H, int dh, int nq,
                   hipStream_t stream) {
   DGVIT_CHECK_ARG(qkv && o && dout && dqkv && B > 0 && N > 0 && H > 0, "attention_bwd: bad arguments");
   DGVIT_CHECK_ARG((long long)B * H < (1ll << 31), "attention_bwd: B*H too large");
   const int nkt = (N + 31) / 32;
   const float scale = 1.0f / sqrtf((float)dh);
-  ATTN_DISPATCH(launch_bwd, qkv, o, dout, dqkv, B, N, H, scale, stream)
+  DGVIT_CHECK_ARG(nq >= 1 && nq <= N, "attention_bwd: bad query count");
+  ATTN_DISPATCH(launch_bwd, qkv, o, dout, dqkv, B, N, H, scale, nq, stream)
   return dgvit_set_error(DGVIT_ERR_ARG, "attention_bwd: unsupported dim_head=%d / tokens=%d", dh, N);
 }

@@ -6,22 +6,23 @@
 #include "common.h"
 
 // kernels implemented in the other translation units
-int layernorm_fwd(const float*, const float*, const float*, float*, float*, float*, int, int, float, hipStream_t);
+int layernorm_fwd(const float*, const float*, const float*, float*, float*, float*, int, int, float, int, hipStream_t);
 int layernorm_bwd_blocks(int T);
 int layernorm_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*,
-                  float*, int, int, hipStream_t);
+                  float*, int, int, int, hipStream_t);
 int rmsnorm_fwd(const float*, long long, const float*, float*, int, int, hipStream_t);
 int rmsnorm_bwd_blocks(int B);
 int rmsnorm_bwd(const float*, const float*, long long, const float*, float*, long long, float*, float*, int, int, hipStream_t);
 int colsum_blocks(int T);
 int colsum(const float*, long long, float*, float*, int, int, int, hipStream_t);
-int attention_fwd(const float*, float*, int, int, int, int, hipStream_t);
-int attention_bwd(const float*, const float*, const float*, float*, int, int, int, int, hipStream_t);
+int attention_fwd(const float*, float*, int, int, int, int, int, hipStream_t);
+int attention_bwd(const float*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 int patchify(const float*, float*, int, int, int, int, int, hipStream_t);
 int goal_row(const float*, const float*, float*, int, int, int, hipStream_t);
 int dropout_inplace(float*, long long, unsigned long long, float, hipStream_t);
 int relu_bwd(const float*, const float*, float*, long long, hipStream_t);
 extern int g_gemm_tile_hint;
+static int g_prune_last = 1;  // last block: only token 0 feeds the output (GoalFormer.py:167)
 
 // ---------------------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
@@ -169,6 +170,7 @@ extern "C" int dgvit_device_count(void) {
   return n;
 }
 extern "C" void dgvit_set_gemm_tile(int tile) { g_gemm_tile_hint = tile; }
+extern "C" void dgvit_set_prune_last_layer(int on) { g_prune_last = on ? 1 : 0; }
 
 // ---------------------------------------------------------------------------------------------- encoder
 extern "C" long long dgvit_got_workspace_floats(const dgvit_config* cfg, int batch, int save) {
@@ -252,28 +254,38 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
     float* lb = ws + w.layer0 + w.layer_stride * i;
     float* xo = (save || !(i & 1)) ? lb + w.xout : ws + w.layer0 + w.layer_floats;
+    // The output only reads token 0 of the last block (GoalFormer.py:167): there, K and V are needed for every
+    // token but Q, the attention output, to_out and the whole feed-forward only for row b*N of each frame.
+    // `tok` = rows processed, `rs` = row step (in token rows) of those rows inside the (T, .) buffers.
+    const bool last = g_prune_last && i == d.L - 1;
+    const int tok = last ? d.B : T, rs = last ? d.N : 1;
     // x = attn(LN(x)) + x   (GoalFormer.py:103, 36-37, 71-82)
-    TRY(layernorm_fwd(x, lp[L_LN1W], lp[L_LN1B], lb + w.ln1, lb + w.mean1, lb + w.rstd1, T, d.D, 1e-5f, st));
-    {
+    TRY(layernorm_fwd(x, lp[L_LN1W], lp[L_LN1B], lb + w.ln1, lb + w.mean1, lb + w.rstd1, T, d.D, 1e-5f, 1, st));
+    if (!last) {
       GemmParams p = gp(lb + w.ln1, d.D, lp[L_QKV], d.D, lb + w.qkv, 3 * d.I, T, 3 * d.I, d.D);
       TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
+    } else {
+      GemmParams kv = gp(lb + w.ln1, d.D, lp[L_QKV] + (long long)d.I * d.D, d.D, lb + w.qkv + d.I, 3 * d.I, T, 2 * d.I, d.D);
+      TRY(gemm_f32(GEMM_NT, EPI_STORE, kv, 1, st));
+      GemmParams q = gp(lb + w.ln1, rs * d.D, lp[L_QKV], d.D, lb + w.qkv, rs * 3 * d.I, tok, d.I, d.D);
+      TRY(gemm_f32(GEMM_NT, EPI_STORE, q, 1, st));
     }
-    TRY(attention_fwd(lb + w.qkv, lb + w.ao, d.B, d.N, d.H, d.dh, st));
+    TRY(attention_fwd(lb + w.qkv, lb + w.ao, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
     {
-      GemmParams p = gp(lb + w.ao, d.I, lp[L_OUTW], d.I, lb + w.xmid, d.D, T, d.D, d.I);
-      p.bias = lp[L_OUTB]; p.res = x; p.ldr = d.D;
+      GemmParams p = gp(lb + w.ao, rs * d.I, lp[L_OUTW], d.I, lb + w.xmid, rs * d.D, tok, d.D, d.I);
+      p.bias = lp[L_OUTB]; p.res = x; p.ldr = rs * d.D;
       TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
     }
     // x = ff(LN(x)) + x     (GoalFormer.py:104, 42-50)
-    TRY(layernorm_fwd(lb + w.xmid, lp[L_LN2W], lp[L_LN2B], lb + w.ln2, lb + w.mean2, lb + w.rstd2, T, d.D, 1e-5f, st));
+    TRY(layernorm_fwd(lb + w.xmid, lp[L_LN2W], lp[L_LN2B], lb + w.ln2, lb + w.mean2, lb + w.rstd2, tok, d.D, 1e-5f, rs, st));
     {
-      GemmParams p = gp(lb + w.ln2, d.D, lp[L_FC1W], d.D, lb + w.h1, d.M, T, d.M, d.D);
+      GemmParams p = gp(lb + w.ln2, rs * d.D, lp[L_FC1W], d.D, lb + w.h1, d.M, tok, d.M, d.D);   // h1 / a1 are dense (tok, M)
       p.bias = lp[L_FC1B]; p.C2 = lb + w.a1; p.ldc2 = d.M;
       TRY(gemm_f32(GEMM_NT, EPI_GELU2, p, 1, st));
     }
     {
-      GemmParams p = gp(lb + w.a1, d.M, lp[L_FC2W], d.M, xo, d.D, T, d.D, d.M);
-      p.bias = lp[L_FC2B]; p.res = lb + w.xmid; p.ldr = d.D;
+      GemmParams p = gp(lb + w.a1, d.M, lp[L_FC2W], d.M, xo, rs * d.D, tok, d.D, d.M);
+      p.bias = lp[L_FC2B]; p.res = lb + w.xmid; p.ldr = rs * d.D;
       TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
     }
     x = xo;
@@ -315,32 +327,45 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
     float* const* lg = grads + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
     const float* lb = ws + w.layer0 + w.layer_stride * i;
     const float* xin = i == 0 ? ws + w.x0 : ws + w.layer0 + w.layer_stride * (i - 1) + w.xout;
+    const bool last = g_prune_last && i == d.L - 1;      // see dgvit_got_forward: only rows b*N carry gradient here
+    const int tok = last ? d.B : T, rs = last ? d.N : 1;
     // ---- feed-forward branch: xout = fc2(gelu(fc1(ln2))) + xmid
-    TRY(wgrad(dx, d.D, lb + w.a1, d.M, lg[L_FC2W], lg[L_FC2B], d.D, d.M, T, slabs, s.slabs_floats, st));
+    TRY(wgrad(dx, rs * d.D, lb + w.a1, d.M, lg[L_FC2W], lg[L_FC2B], d.D, d.M, tok, slabs, s.slabs_floats, st));
     {
-      GemmParams p = gp(dx, d.D, lp[L_FC2W], d.M, dh1, d.M, T, d.M, d.D);
+      GemmParams p = gp(dx, rs * d.D, lp[L_FC2W], d.M, dh1, d.M, tok, d.M, d.D);
       p.aux = lb + w.h1; p.ldaux = d.M;
       TRY(gemm_f32(GEMM_NN, EPI_DGELU, p, 1, st));  // dh1 = (dx W2) * gelu'(h1)
     }
-    TRY(wgrad(dh1, d.M, lb + w.ln2, d.D, lg[L_FC1W], lg[L_FC1B], d.M, d.D, T, slabs, s.slabs_floats, st));
+    TRY(wgrad(dh1, d.M, lb + w.ln2, rs * d.D, lg[L_FC1W], lg[L_FC1B], d.M, d.D, tok, slabs, s.slabs_floats, st));
     {
-      GemmParams p = gp(dh1, d.M, lp[L_FC1W], d.D, dln, d.D, T, d.D, d.M);
+      GemmParams p = gp(dh1, d.M, lp[L_FC1W], d.D, dln, rs * d.D, tok, d.D, d.M);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dln2 = dh1 W1
     }
-    TRY(layernorm_bwd(dln, lb + w.xmid, lb + w.mean2, lb + w.rstd2, lp[L_LN2W], dx, dx2, lg[L_LN2W], lg[L_LN2B], part, T, d.D, st));
+    if (last) HIP_TRY(hipMemsetAsync(dx2, 0, sizeof(float) * d.T * d.D, st));   // rows other than b*N get no gradient
+    TRY(layernorm_bwd(dln, lb + w.xmid, lb + w.mean2, lb + w.rstd2, lp[L_LN2W], dx, dx2, lg[L_LN2W], lg[L_LN2B], part, tok, d.D, rs, st));
     // ---- attention branch: xmid = to_out(attn(to_qkv(ln1))) + xin       (dx2 = d xmid)
-    TRY(wgrad(dx2, d.D, lb + w.ao, d.I, lg[L_OUTW], lg[L_OUTB], d.D, d.I, T, slabs, s.slabs_floats, st));
+    TRY(wgrad(dx2, rs * d.D, lb + w.ao, rs * d.I, lg[L_OUTW], lg[L_OUTB], d.D, d.I, tok, slabs, s.slabs_floats, st));
     {
-      GemmParams p = gp(dx2, d.D, lp[L_OUTW], d.I, dao, d.I, T, d.I, d.D);
+      GemmParams p = gp(dx2, rs * d.D, lp[L_OUTW], d.I, dao, rs * d.I, tok, d.I, d.D);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dao = dxmid Wo
     }
-    TRY(attention_bwd(lb + w.qkv, lb + w.ao, dao, dqkv, d.B, d.N, d.H, d.dh, st));
-    TRY(wgrad(dqkv, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV], nullptr, 3 * d.I, d.D, T, slabs, s.slabs_floats, st));
-    {
+    TRY(attention_bwd(lb + w.qkv, lb + w.ao, dao, dqkv, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
+    if (!last) {
+      TRY(wgrad(dqkv, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV], nullptr, 3 * d.I, d.D, T, slabs, s.slabs_floats, st));
       GemmParams p = gp(dqkv, 3 * d.I, lp[L_QKV], d.D, dln, d.D, T, d.D, 3 * d.I);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dln1 = dqkv Wqkv
+    } else {
+      // dWq from the token-0 rows, dWk/dWv from all rows; dln1 = dkv Wkv (+ dq Wq on the token-0 rows)
+      TRY(wgrad(dqkv, rs * 3 * d.I, lb + w.ln1, rs * d.D, lg[L_QKV], nullptr, d.I, d.D, tok, slabs, s.slabs_floats, st));
+      TRY(wgrad(dqkv + d.I, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV] + (long long)d.I * d.D, nullptr, 2 * d.I, d.D, T, slabs,
+                s.slabs_floats, st));
+      GemmParams kv = gp(dqkv + d.I, 3 * d.I, lp[L_QKV] + (long long)d.I * d.D, d.D, dln, d.D, T, d.D, 2 * d.I);
+      TRY(gemm_f32(GEMM_NN, EPI_STORE, kv, 1, st));
+      GemmParams q = gp(dqkv, rs * 3 * d.I, lp[L_QKV], d.D, dln, rs * d.D, tok, d.D, d.I);
+      q.res = dln; q.ldr = rs * d.D;
+      TRY(gemm_f32(GEMM_NN, EPI_STORE, q, 1, st));
     }
-    TRY(layernorm_bwd(dln, xin, lb + w.mean1, lb + w.rstd1, lp[L_LN1W], dx2, dx, lg[L_LN1W], lg[L_LN1B], part, T, d.D, st));
+    TRY(layernorm_bwd(dln, xin, lb + w.mean1, lb + w.rstd1, lp[L_LN1W], dx2, dx, lg[L_LN1W], lg[L_LN1B], part, T, d.D, 1, st));
   }
   // ---- token assembly: x0 = dropout(cat(goal, patches W^T + b) + pos)
   if (keep < 1.f) TRY(dropout_inplace(dx, d.T * d.D, seed, keep, st));
@@ -422,7 +447,7 @@ extern "C" int dgvit_gemm(int layout, int epilogue, const float* A, int lda, con
 
 extern "C" int dgvit_layernorm_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                                        int rows, int D, void* stream) {
-  return layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, 1e-5f, (hipStream_t)stream);
+  return layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, 1e-5f, 1, (hipStream_t)stream);
 }
 extern "C" long long dgvit_layernorm_backward_scratch_floats(int rows, int D) {
   if (rows <= 0 || D <= 0) return -1;
@@ -433,7 +458,7 @@ extern "C" int dgvit_layernorm_backward(const float* dy, const float* x, const f
                                         long long scratch_floats, int rows, int D, void* stream) {
   if (scratch_floats < dgvit_layernorm_backward_scratch_floats(rows, D))
     return dgvit_set_error(DGVIT_ERR_WORKSPACE, "layernorm_backward: scratch too small");
-  return layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, scratch, rows, D, (hipStream_t)stream);
+  return layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, scratch, rows, D, 1, (hipStream_t)stream);
 }
 extern "C" int dgvit_rmsnorm_forward(const float* x, long long ldx, const float* g, float* y, int rows, int D, void* stream) {
   return rmsnorm_fwd(x, ldx, g, y, rows, D, (hipStream_t)stream);
@@ -449,11 +474,11 @@ extern "C" int dgvit_rmsnorm_backward(const float* dy, const float* x, long long
   return rmsnorm_bwd(dy, x, ldx, g, dx, lddx, dg, scratch, rows, D, (hipStream_t)stream);
 }
 extern "C" int dgvit_attention_forward(const float* qkv, float* out, int B, int N, int H, int dh, void* stream) {
-  return attention_fwd(qkv, out, B, N, H, dh, (hipStream_t)stream);
+  return attention_fwd(qkv, out, B, N, H, dh, N, (hipStream_t)stream);
 }
 extern "C" int dgvit_attention_backward(const float* qkv, const float* out, const float* dout, float* dqkv, int B, int N, int H,
                                         int dh, void* stream) {
-  return attention_bwd(qkv, out, dout, dqkv, B, N, H, dh, (hipStream_t)stream);
+  return attention_bwd(qkv, out, dout, dqkv, B, N, H, dh, N, (hipStream_t)stream);
 }
 extern "C" int dgvit_patchify(const float* img, float* patches, int B, int ih, int iw, int ph, int pw, void* stream) {
   return patchify(img, patches, B, ih, iw, ph, pw, (hipStream_t)stream);

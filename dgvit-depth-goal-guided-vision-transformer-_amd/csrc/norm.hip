@@ -12,11 +12,11 @@ namespace {
 __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd, int T, int D,
-                                                            float eps) {
+                                                            float eps, int rs) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= T) return;
-  const float* xr = x + (long long)row * D;
+  const float* xr = x + (long long)row * rs * D;   // logical row r lives at physical row r*rs (rs = N: token 0 of every frame)
   float s = 0.f;
   for (int c = lane * 4; c < D; c += 256) {
     const float4 v = *reinterpret_cast<const float4*>(xr + c);
@@ -29,22 +29,22 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restr
     const float a = v.x - mu, b = v.y - mu, cc = v.z - mu, d = v.w - mu;
     q += (a * a + b * b) + (cc * cc + d * d);
   }
-  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
-  float* yr = y + (long long)row * D;
+  const float rsd = rsqrtf(wave_sum(q) / (float)D + eps);
+  float* yr = y + (long long)row * rs * D;
   for (int c = lane * 4; c < D; c += 256) {
     const float4 v = *reinterpret_cast<const float4*>(xr + c);
     const float4 g = *reinterpret_cast<const float4*>(gamma + c);
     const float4 b = *reinterpret_cast<const float4*>(beta + c);
     float4 o;
-    o.x = (v.x - mu) * rs * g.x + b.x;
-    o.y = (v.y - mu) * rs * g.y + b.y;
-    o.z = (v.z - mu) * rs * g.z + b.z;
-    o.w = (v.w - mu) * rs * g.w + b.w;
+    o.x = (v.x - mu) * rsd * g.x + b.x;
+    o.y = (v.y - mu) * rsd * g.y + b.y;
+    o.z = (v.z - mu) * rsd * g.z + b.z;
+    o.w = (v.w - mu) * rsd * g.w + b.w;
     *reinterpret_cast<float4*>(yr + c) = o;
   }
   if (lane == 0) {
     mean[row] = mu;
-    rstd[row] = rs;
+    rstd[row] = rsd;
   }
 }
 
@@ -55,7 +55,8 @@ template <int NCH>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                            float* __restrict__ dx, float* __restrict__ partial, int T, int D) {
+                                                            float* __restrict__ dx, float* __restrict__ partial, int T, int D,
+                                                            int rs) {
   __shared__ float red[4][2][NCH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 ag[NCH], ab[NCH], gm[NCH];
@@ -68,8 +69,8 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
   }
   const float invD = 1.f / (float)D;
   for (int row = blockIdx.x * 4 + wave; row < T; row += gridDim.x * 4) {
-    const long long off = (long long)row * D;
-    const float mu = mean[row], rs = rstd[row];
+    const long long off = (long long)row * rs * D;
+    const float mu = mean[row], rsd = rstd[row];
     float4 g[NCH], xh[NCH];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
       if (c < D) {
         const float4 d = *reinterpret_cast<const float4*>(dy + off + c);
         const float4 v = *reinterpret_cast<const float4*>(x + off + c);
-        xh[i] = make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs);
+        xh[i] = make_float4((v.x - mu) * rsd, (v.y - mu) * rsd, (v.z - mu) * rsd, (v.w - mu) * rsd);
         ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
         ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
         g[i] = make_float4(d.x * gm[i].x, d.y * gm[i].y, d.z * gm[i].z, d.w * gm[i].w);
@@ -94,10 +95,10 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
       const int c = lane * 4 + i * 256;
       if (c < D) {
         float4 o;
-        o.x = rs * (g[i].x - c1 - xh[i].x * c2);
-        o.y = rs * (g[i].y - c1 - xh[i].y * c2);
-        o.z = rs * (g[i].z - c1 - xh[i].z * c2);
-        o.w = rs * (g[i].w - c1 - xh[i].w * c2);
+        o.x = rsd * (g[i].x - c1 - xh[i].x * c2);
+        o.y = rsd * (g[i].y - c1 - xh[i].y * c2);
+        o.z = rsd * (g[i].z - c1 - xh[i].z * c2);
+        o.w = rsd * (g[i].w - c1 - xh[i].w * c2);
         if (dres) {
           const float4 r = *reinterpret_cast<const float4*>(dres + off + c);
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
@@ -193,10 +194,11 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ a
 }  // namespace
 
 int layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int T, int D,
-                  float eps, hipStream_t stream) {
+                  float eps, int rs, hipStream_t stream) {
   DGVIT_CHECK_ARG(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
   DGVIT_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0, "layernorm_fwd: D=%d must be a positive multiple of 4", D);
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, T, D, eps);
+  DGVIT_CHECK_ARG(rs >= 1, "layernorm_fwd: bad row step");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, mean, rstd, T, D, eps, rs);
   DGVIT_CHECK_LAUNCH("layernorm_fwd");
   return DGVIT_OK;
 }
@@ -205,13 +207,13 @@ int layernorm_bwd_blocks(int T) { return T < 2048 ? (T + 3) / 4 : 512; }
 
 // partial must hold layernorm_bwd_blocks(T) * 2 * D floats; dgamma/dbeta are written (not accumulated)
 int layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
-                  float* dx, float* dgamma, float* dbeta, float* partial, int T, int D, hipStream_t stream) {
+                  float* dx, float* dgamma, float* dbeta, float* partial, int T, int D, int rs, hipStream_t stream) {
   DGVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && partial, "layernorm_bwd: null pointer");
   DGVIT_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bwd: D=%d must be a multiple of 4, <= 1024", D);
   const int nb = layernorm_bwd_blocks(T);
   const int nch = (D + 255) / 256;
 #define LNB(NCH)                                                                                                              \
-  hipLaunchKernelGGL(layernorm_bwd_kernel<NCH>, dim3(nb), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dres, dx, partial, T, D)
+  hipLaunchKernelGGL(layernorm_bwd_kernel<NCH>, dim3(nb), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dres, dx, partial, T, D, rs)
   if (nch == 1) LNB(1);
   else if (nch == 2) LNB(2);
   else if (nch == 3) LNB(3);

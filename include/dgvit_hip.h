@@ -115,8 +115,12 @@ long long dgvit_gemm_scratch_floats(int layout, int M, int N, int K);
 int dgvit_gemm(int layout, int epilogue, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
                int N, int K, const float* bias, const float* res, int ldr, float* C2, int ldc2, const float* aux,
                int ldaux, float* scratch, long long scratch_floats, void* stream);
-/* test/bench knob: force the GEMM workgroup tile (0 = automatic, 64, 128) */
+/* test/bench knob: force the GEMM workgroup tile (0 = automatic; BM*1000000 + BN*1000 + BK, e.g. 128128032) */
 void dgvit_set_gemm_tile(int tile);
+/* The output reads only token 0 of the last block (GoalFormer.py:167), so by default that block computes Q,
+ * attention output, to_out and the feed-forward for one row per frame (K/V for all) -- identical results, fewer
+ * FLOPs.  0 switches this off (dense last block, for A/B measurements). */
+void dgvit_set_prune_last_layer(int on);
 
 /* nn.LayerNorm(D), eps 1e-5 (GoalFormer.py:34,37): y, and the per-row mean / rstd saved for backward */
 int dgvit_layernorm_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

@@ -204,3 +204,32 @@ def test_full_size_properties(amd):
         avg = 0.5 * (ga[k] + gb[k])
         scale = max(gf[k].abs().max().item(), 1e-6)
         assert (gf[k] - avg).abs().max().item() <= 2e-3 * scale + 1e-7, k
+
+
+def test_last_block_token0_schedule_equals_dense(amd):
+    """The last block computes Q / attention / to_out / feed-forward for token 0 only (GoalFormer.py:167 reads
+    x[:, 0]); outputs and every gradient must equal the dense schedule (dgvit_set_prune_last_layer(0))."""
+    lib = amd.load_library()
+    cfg = O.GoTConfig(image=(84, 84), patch=(12, 12), dim=256, depth=3, heads=8)
+    params = O.make_params(O.policy_param_spec(cfg), 31)
+    m = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, image_size=cfg.image, patch_size=cfg.patch), params).eval().to("cuda")
+    img, pstate, _, _ = (t.cuda() for t in O.make_inputs(cfg, 37, 31))
+
+    def run():
+        m.zero_grad()
+        mean, log_std = m([img, pstate])
+        ((mean ** 2).mean() + (log_std ** 2).mean()).backward()
+        return mean.detach().clone(), log_std.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    try:
+        lib.dgvit_set_prune_last_layer(0)
+        md, ld, gd = run()
+    finally:
+        lib.dgvit_set_prune_last_layer(1)
+    mp_, lp_, gp_ = run()
+    np.testing.assert_allclose(mp_.cpu().numpy(), md.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(lp_.cpu().numpy(), ld.cpu().numpy(), rtol=0, atol=2e-6)
+    assert gd.keys() == gp_.keys()
+    for k in gd:
+        scale = max(gd[k].abs().max().item(), 1e-8)
+        assert (gd[k] - gp_[k]).abs().max().item() <= 2e-4 * scale + 1e-9, k
