@@ -152,6 +152,12 @@ def main():
         fps = frames / dt
         fwd = cfg.fwd_flops_per_frame()
         gemm_tflops = (work[0] / 1e12) / (ms[0] / 1e3) if ms[0] > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (tools/pmc_traffic.py)
+            with open(os.path.join(ROOT, "profiles", "r01_c_hbm_traffic.json")) as f:
+                traffic = json.load(f)["kernels"]["gemm_f32_kernel"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "depth frames/sec through DGViT fwd+bwd, batch 512x84x84",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -162,7 +168,8 @@ def main():
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "gflop_per_frame_fwd_bwd": round(3 * fwd / 1e9, 4)},
             "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(gemm_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(gemm_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes (profiles/r01_c_hbm_traffic.json)",
                          "kernel": "gemm_f32_kernel (all instantiations: NT fwd, NN dgrad, TN wgrad)",
                          "launches_per_step": int(cnt[0] // max(1, args.steps)),
                          "avg_launch_ms": round(ms[0] / max(1, cnt[0]), 5),

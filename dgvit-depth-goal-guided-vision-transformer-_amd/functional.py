@@ -80,7 +80,14 @@ class _GoTEncoder(torch.autograd.Function):
         dfeat = _dev(dfeat, "dfeat")
         B = ctx.batch
         dev = dfeat.device
-        grads = [torch.empty_like(p) for p in params]
+        # all parameter gradients are views of ONE flat buffer: autograd adopts them as .grad without a copy, and
+        # parallel.GradSync all-reduces the buffer in place (one large RCCL call instead of 70 small tensors)
+        sizes = [p.numel() for p in params]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + ((n + 3) & ~3))          # keep every view 16-byte aligned
+        flat = torch.empty(offs[-1], dtype=torch.float32, device=dev)
+        grads = [flat[o:o + n].view_as(p) for o, n, p in zip(offs, sizes, params)]
         dgoal = torch.empty(B, cfg.dim, dtype=torch.float32, device=dev)
         nsc = lib.dgvit_got_backward_scratch_floats(ctypes.byref(cfg), B)
         scratch = torch.empty(nsc, dtype=torch.float32, device=dev)

@@ -2,13 +2,14 @@
 ``torch.distributed`` (backend "nccl" = RCCL over xGMI on MI355X, "gloo" on CPU for tests).
 
 Every frame is encoded independently, so rank r simply takes its own frames; the only
-exchange is one all-reduce(sum)/world of the gradients after backward.  The gradients of all parameters that
-receive one live in ONE flat fp32 buffer (``p.grad`` are views into it), so the exchange is a few large
-bucketed all-reduces -- sized for xGMI's per-link ring bandwidth -- with no flatten/unflatten copies.
-Parameters that never get a gradient (``cls_token``, ``mlp_head.*``, the dead ``conv1-3``) are
-discovered on the first call and left out.
+exchange is one all-reduce(sum)/world of the gradients after backward.  The fused encoder backward already
+writes all its parameter gradients into ONE flat fp32 buffer (``functional._GoTEncoder.backward``); ``sync()``
+finds such shared buffers through the gradients' storages and all-reduces them in place -- a few large
+collectives sized for xGMI's per-link ring bandwidth, no flatten/unflatten copies.  The remaining small
+gradients (head Linears) are coalesced into one extra buffer.  Parameters that never get a gradient
+(``cls_token``, ``mlp_head.*``, the dead ``conv1-3``) simply have ``grad is None`` and are skipped.
 """
-from typing import Iterable, List, Optional
+from typing import Iterable, List
 
 import torch
 import torch.distributed as dist
@@ -25,9 +26,7 @@ class GradSync:
                     self.params.append(p)
         self.group = process_group
         self.bucket_elems = max(1, bucket_bytes // 4)
-        self.flat: Optional[torch.Tensor] = None
-        self.live: List[torch.nn.Parameter] = []
-        self.views: List[torch.Tensor] = []
+        self._last_numel = 0
 
     @property
     def world(self) -> int:
@@ -40,49 +39,64 @@ class GradSync:
         for p in self.params:
             dist.broadcast(p.data, src=src, group=self.group)
 
-    def _adopt(self) -> None:
-        """Move the existing .grad tensors into one flat buffer and re-point .grad at views of it."""
-        self.live = [p for p in self.params if p.grad is not None]
-        total = sum(p.numel() for p in self.live)
-        if total == 0:
-            raise RuntimeError("GradSync: no parameter has a gradient; call after backward()")
-        ref = self.live[0]
-        self.flat = torch.zeros(total, dtype=ref.grad.dtype, device=ref.grad.device)
-        self.views, off = [], 0
-        for p in self.live:
-            v = self.flat[off:off + p.numel()].view_as(p)
-            v.copy_(p.grad)
-            p.grad = v
-            self.views.append(v)
-            off += p.numel()
-
-    def _intact(self) -> bool:
-        return self.flat is not None and all(p.grad is v for p, v in zip(self.live, self.views)) and \
-            all(p.grad is None for p in self.params if all(p is not q for q in self.live))
-
     def zero_grad(self) -> None:
-        """Zero the flat buffer in one kernel, keeping .grad views alive (use instead of optimizer.zero_grad())."""
-        if self.flat is None:
-            for p in self.params:
-                p.grad = None
-        else:
-            self.flat.zero_()
+        """Drop the gradients (set to None): the next backward's tensors are adopted as .grad without any
+        accumulate or fill kernel.  Use instead of optimizer.zero_grad()."""
+        for p in self.params:
+            p.grad = None
+
+    def _regions(self):
+        """Group live gradients by storage; a group covering one contiguous range is reduced in place."""
+        by_storage = {}
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                continue
+            if not g.is_contiguous():
+                g = p.grad = g.contiguous()
+            by_storage.setdefault(g.untyped_storage().data_ptr(), []).append(g)
+        shared, loose = [], []
+        for gs in by_storage.values():
+            if len(gs) == 1:
+                loose.append(gs[0])
+                continue
+            lo = min(g.storage_offset() for g in gs)
+            hi = max(g.storage_offset() + g.numel() for g in gs)
+            flat = torch.empty(0, dtype=gs[0].dtype, device=gs[0].device).set_(gs[0].untyped_storage(), lo, (hi - lo,))
+            shared.append(flat)
+        return shared, loose
 
     def sync(self) -> None:
         """All-reduce(sum)/world the gradients; call once after backward."""
-        if self.flat is None or not self._intact():
-            self._adopt()
+        shared, loose = self._regions()
+        self._last_numel = sum(p.grad.numel() for p in self.params if p.grad is not None)
+        if self._last_numel == 0:
+            raise RuntimeError("GradSync: no parameter has a gradient; call after backward()")
         w = self.world
         if w == 1:
             return
-        handles = []
-        n = self.flat.numel()
-        for off in range(0, n, self.bucket_elems):
-            chunk = self.flat[off:min(n, off + self.bucket_elems)]
-            handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        handles, bufs = [], list(shared)
+        small = None
+        if loose:
+            small = torch.cat([g.reshape(-1) for g in loose])
+            bufs.append(small)
+        for buf in bufs:
+            n = buf.numel()
+            for off in range(0, n, self.bucket_elems):
+                chunk = buf[off:min(n, off + self.bucket_elems)]
+                handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for h in handles:
             h.wait()
-        self.flat.div_(w)
+        inv = 1.0 / w
+        for buf in shared:
+            buf.mul_(inv)
+        if small is not None:
+            small.mul_(inv)
+            off = 0
+            for g in loose:
+                g.copy_(small[off:off + g.numel()].view_as(g))
+                off += g.numel()
 
     def grad_numel(self) -> int:
-        return 0 if self.flat is None else self.flat.numel()
+        """Number of gradient elements exchanged by the last sync()."""
+        return self._last_numel

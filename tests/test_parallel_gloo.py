@@ -59,11 +59,30 @@ def _worker(rank, world, port, out):
             mean, log_std = net(img[sl], pstate[sl])
             ((mean ** 2).mean() + (log_std ** 2).mean()).backward()
             sync.sync()
-        grads = {k: getattr(net, n).grad for k, n in net.keys}
+        grads = {k: getattr(net, n).grad.clone() if getattr(net, n).grad is not None else None for k, n in net.keys}
         state = {k: getattr(net, n).detach().clone() for k, n in net.keys}
+        n_live = sync.grad_numel()
+        # shared-storage path: gradients that are views of one flat buffer (what the fused HIP backward
+        # produces) must be all-reduced IN PLACE, together with a few loose tensors
+        plist = list(net.parameters())
+        for q in plist:
+            q.grad = None
+        members, loose = plist[:6], plist[6:9]
+        flat = torch.full((sum(q.numel() for q in members),), float(rank + 1))
+        off = 0
+        for q in members:
+            q.grad = flat[off:off + q.numel()].view_as(q)
+            off += q.numel()
+        for q in loose:
+            q.grad = torch.full_like(q, 10.0 * (rank + 1))
+        sync.sync()
+        assert torch.all(flat == 1.5), "flat buffer was not reduced in place"
+        assert all(q.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for q in members)
+        assert all(torch.all(q.grad == 15.0) for q in loose)
+        assert sync.grad_numel() == flat.numel() + sum(q.numel() for q in loose)
         # numpy payloads: torch tensors would travel as shared-memory handles that die with the worker
         out.put((rank, {k: (None if g is None else g.numpy().copy()) for k, g in grads.items()},
-                 {k: v.numpy().copy() for k, v in state.items()}, sync.grad_numel()))
+                 {k: v.numpy().copy() for k, v in state.items()}, n_live))
     finally:
         dist.destroy_process_group()
 
