@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--wgrad-overlap", action="store_true", help="A/B: weight-gradient GEMMs on the helper stream (+5%% frames/s, blurs per-kernel timing)")
+    ap.add_argument("--dense-last-block", action="store_true", help="A/B: compute the last block for every token")
     return ap.parse_args()
 
 
@@ -98,6 +100,8 @@ def main():
     from dgvit_amd import _lib
     from oracle import dgvit_oracle as O   # inputs + FLOP model + cpu_baseline only; never on the measured path
     lib = dgvit_amd.load_library()
+    lib.dgvit_set_wgrad_overlap(1 if args.wgrad_overlap else 0)
+    lib.dgvit_set_prune_last_layer(0 if args.dense_last_block else 1)
 
     cfg = O.GoTConfig(image=IMAGE, patch=PATCH, dim=DIM, depth=DEPTH, heads=HEADS)
     B = args.batch
@@ -166,7 +170,9 @@ def main():
             "config": {"workload": "C3: GoTPolicy DGViT-small (84x84@12x12, L6 H8 D256 M2048, N=50 tokens) actor fwd+bwd, "
                                    "train mode (emb dropout 0.1), MSE-to-random-target loss, grad all-reduce + Adam step",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "gflop_per_frame_fwd_bwd": round(3 * fwd / 1e9, 4)},
+                       "gflop_per_frame_fwd_bwd": round(3 * fwd / 1e9, 4),
+                       "last_block": "dense" if args.dense_last_block else "token-0 rows only (identical results; FLOPs counted dense)",
+                       "wgrad_overlap": bool(args.wgrad_overlap)},
             "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes (profiles/r01_c_hbm_traffic.json)",

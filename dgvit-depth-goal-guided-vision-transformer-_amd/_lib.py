@@ -44,6 +44,7 @@ SIGNATURES = {
     "dgvit_gemm": (_I, [_I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P, _LL, _P]),
     "dgvit_set_gemm_tile": (None, [_I]),
     "dgvit_set_prune_last_layer": (None, [_I]),
+    "dgvit_set_wgrad_overlap": (None, [_I]),
     "dgvit_layernorm_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dgvit_layernorm_backward_scratch_floats": (_LL, [_I, _I]),
     "dgvit_layernorm_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _P]),

@@ -69,11 +69,25 @@ int reduce_slabs(const float* slabs, float* out, long long n, int nslab, long lo
 int reduce_slabs2(const float* slabs, float* out1, long long n1, float* out2, long long n, int nslab, long long slab_stride,
                   hipStream_t stream);
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf with |abs error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26) on v_rcp_f32 / v_exp_f32: ~13 VALU instructions
+// instead of ~37 for ocml's erff (5.5e-7 once evaluated in fp32).  GELU(x) and GELU'(x) built on it stay within ~5e-7 of the exact-erf forms for
+// |x| <= 6 (checked against fp64 in tests/test_gpu_ops.py::test_gemm_epilogues), far inside the 1e-4 parity gate.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  return copysignf(fmaf(-p, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+  return fmaf(x, pdf, cdf);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

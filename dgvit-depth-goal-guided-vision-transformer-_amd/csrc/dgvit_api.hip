@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "../../include/dgvit_hip.h"
 #include "common.h"
 
@@ -23,6 +25,42 @@ int dropout_inplace(float*, long long, unsigned long long, float, hipStream_t);
 int relu_bwd(const float*, const float*, float*, long long, hipStream_t);
 extern int g_gemm_tile_hint;
 static int g_prune_last = 1;  // last block: only token 0 feeds the output (GoalFormer.py:167)
+static int g_overlap_wgrad = 0;  // opt-in: run weight-gradient GEMMs on a helper stream beside the data-gradient chain
+
+// ---------------------------------------------------------------------------------------------- helper stream
+// dgvit_got_backward forks every weight-gradient GEMM (+ its slab reduction) onto one internal non-blocking
+// stream and joins it back with events, so the wgrad workgroups fill the tail / prologue bubbles of the
+// data-gradient kernels on the caller's stream.  All ordering is event based (capturable into a hipGraph);
+// the helper stream and a ring of events are created on first use and live for the process.
+namespace {
+struct Side {
+  hipStream_t stream = nullptr;
+  hipEvent_t ring[32];
+  unsigned next = 0;
+  bool ready = false;
+};
+Side g_side;
+std::mutex g_side_mu;
+
+int side_init() {
+  std::lock_guard<std::mutex> lk(g_side_mu);
+  if (g_side.ready) return DGVIT_OK;
+  if (hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) != hipSuccess)
+    return dgvit_set_error(DGVIT_ERR_HIP, "cannot create the helper stream");
+  for (auto& e : g_side.ring)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess)
+      return dgvit_set_error(DGVIT_ERR_HIP, "cannot create helper events");
+  g_side.ready = true;
+  return DGVIT_OK;
+}
+// `to` waits for everything enqueued on `from` so far
+int chain(hipStream_t from, hipStream_t to) {
+  hipEvent_t e = g_side.ring[g_side.next++ % 32];
+  if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess)
+    return dgvit_set_error(DGVIT_ERR_HIP, "event fork/join failed");
+  return DGVIT_OK;
+}
+}  // namespace
 
 // ---------------------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
@@ -171,6 +209,7 @@ extern "C" int dgvit_device_count(void) {
 }
 extern "C" void dgvit_set_gemm_tile(int tile) { g_gemm_tile_hint = tile; }
 extern "C" void dgvit_set_prune_last_layer(int on) { g_prune_last = on ? 1 : 0; }
+extern "C" void dgvit_set_wgrad_overlap(int on) { g_overlap_wgrad = on ? 1 : 0; }
 
 // ---------------------------------------------------------------------------------------------- encoder
 extern "C" long long dgvit_got_workspace_floats(const dgvit_config* cfg, int batch, int save) {
@@ -317,6 +356,17 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
   float* part = scratch + s.part;
   float* slabs = scratch + s.slabs;
 
+  // weight gradients run on the helper stream `sw`; `done[j]` = main must wait for the previous layer's j-th
+  // wgrad before overwriting the buffer it reads (dx, dh1, dx2, dqkv)
+  hipStream_t sw = st;
+  if (g_overlap_wgrad) {
+    TRY(side_init());
+    sw = g_side.stream;
+    TRY(chain(st, sw));   // helper starts after everything already queued by the caller
+  }
+  auto fork = [&]() -> int { return sw == st ? DGVIT_OK : chain(st, sw); };
+  auto join = [&]() -> int { return sw == st ? DGVIT_OK : chain(sw, st); };
+
   // RMSNorm on token 0 of the last layer's output; every other token row gets zero gradient
   const float* xl = ws + w.layer0 + w.layer_stride * (d.L - 1) + w.xout;
   HIP_TRY(hipMemsetAsync(dx, 0, sizeof(float) * d.T * d.D, st));
@@ -330,13 +380,17 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
     const bool last = g_prune_last && i == d.L - 1;      // see dgvit_got_forward: only rows b*N carry gradient here
     const int tok = last ? d.B : T, rs = last ? d.N : 1;
     // ---- feed-forward branch: xout = fc2(gelu(fc1(ln2))) + xmid
-    TRY(wgrad(dx, rs * d.D, lb + w.a1, d.M, lg[L_FC2W], lg[L_FC2B], d.D, d.M, tok, slabs, s.slabs_floats, st));
+    // (helper-stream kernels are ordered among themselves, so the slab scratch is reused safely; a `join` before
+    //  a main-stream kernel that overwrites a buffer makes sure the wgrads that read it have finished)
+    TRY(fork());
+    TRY(wgrad(dx, rs * d.D, lb + w.a1, d.M, lg[L_FC2W], lg[L_FC2B], d.D, d.M, tok, slabs, s.slabs_floats, sw));
     {
       GemmParams p = gp(dx, rs * d.D, lp[L_FC2W], d.M, dh1, d.M, tok, d.M, d.D);
       p.aux = lb + w.h1; p.ldaux = d.M;
-      TRY(gemm_f32(GEMM_NN, EPI_DGELU, p, 1, st));  // dh1 = (dx W2) * gelu'(h1)
+      TRY(gemm_f32(GEMM_NN, EPI_DGELU, p, 1, st));  // dh1 = (dx W2) * gelu'(h1)   [previous layer's wgrads joined below]
     }
-    TRY(wgrad(dh1, d.M, lb + w.ln2, rs * d.D, lg[L_FC1W], lg[L_FC1B], d.M, d.D, tok, slabs, s.slabs_floats, st));
+    TRY(fork());
+    TRY(wgrad(dh1, d.M, lb + w.ln2, rs * d.D, lg[L_FC1W], lg[L_FC1B], d.M, d.D, tok, slabs, s.slabs_floats, sw));
     {
       GemmParams p = gp(dh1, d.M, lp[L_FC1W], d.D, dln, rs * d.D, tok, d.D, d.M);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dln2 = dh1 W1
@@ -344,27 +398,32 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
     if (last) HIP_TRY(hipMemsetAsync(dx2, 0, sizeof(float) * d.T * d.D, st));   // rows other than b*N get no gradient
     TRY(layernorm_bwd(dln, lb + w.xmid, lb + w.mean2, lb + w.rstd2, lp[L_LN2W], dx, dx2, lg[L_LN2W], lg[L_LN2B], part, tok, d.D, rs, st));
     // ---- attention branch: xmid = to_out(attn(to_qkv(ln1))) + xin       (dx2 = d xmid)
-    TRY(wgrad(dx2, rs * d.D, lb + w.ao, rs * d.I, lg[L_OUTW], lg[L_OUTB], d.D, d.I, tok, slabs, s.slabs_floats, st));
+    TRY(fork());
+    TRY(wgrad(dx2, rs * d.D, lb + w.ao, rs * d.I, lg[L_OUTW], lg[L_OUTB], d.D, d.I, tok, slabs, s.slabs_floats, sw));
     {
       GemmParams p = gp(dx2, rs * d.D, lp[L_OUTW], d.I, dao, rs * d.I, tok, d.I, d.D);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dao = dxmid Wo
     }
     TRY(attention_bwd(lb + w.qkv, lb + w.ao, dao, dqkv, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
+    TRY(fork());
     if (!last) {
-      TRY(wgrad(dqkv, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV], nullptr, 3 * d.I, d.D, T, slabs, s.slabs_floats, st));
+      TRY(wgrad(dqkv, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV], nullptr, 3 * d.I, d.D, T, slabs, s.slabs_floats, sw));
       GemmParams p = gp(dqkv, 3 * d.I, lp[L_QKV], d.D, dln, d.D, T, d.D, 3 * d.I);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dln1 = dqkv Wqkv
     } else {
       // dWq from the token-0 rows, dWk/dWv from all rows; dln1 = dkv Wkv (+ dq Wq on the token-0 rows)
-      TRY(wgrad(dqkv, rs * 3 * d.I, lb + w.ln1, rs * d.D, lg[L_QKV], nullptr, d.I, d.D, tok, slabs, s.slabs_floats, st));
+      TRY(wgrad(dqkv, rs * 3 * d.I, lb + w.ln1, rs * d.D, lg[L_QKV], nullptr, d.I, d.D, tok, slabs, s.slabs_floats, sw));
       TRY(wgrad(dqkv + d.I, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV] + (long long)d.I * d.D, nullptr, 2 * d.I, d.D, T, slabs,
-                s.slabs_floats, st));
+                s.slabs_floats, sw));
       GemmParams kv = gp(dqkv + d.I, 3 * d.I, lp[L_QKV] + (long long)d.I * d.D, d.D, dln, d.D, T, d.D, 2 * d.I);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, kv, 1, st));
       GemmParams q = gp(dqkv, rs * 3 * d.I, lp[L_QKV], d.D, dln, rs * d.D, tok, d.D, d.I);
       q.res = dln; q.ldr = rs * d.D;
       TRY(gemm_f32(GEMM_NN, EPI_STORE, q, 1, st));
     }
+    // dx, dh1, dx2 and dqkv are overwritten from here on (this LayerNorm backward and the next layer): wait for the
+    // helper stream.  Only this layer's last wgrad (qkv) can still be running; it overlapped the dln1 GEMM above.
+    TRY(join());
     TRY(layernorm_bwd(dln, xin, lb + w.mean1, lb + w.rstd1, lp[L_LN1W], dx2, dx, lg[L_LN1W], lg[L_LN1B], part, T, d.D, 1, st));
   }
   // ---- token assembly: x0 = dropout(cat(goal, patches W^T + b) + pos)

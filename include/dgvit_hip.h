@@ -121,6 +121,11 @@ void dgvit_set_gemm_tile(int tile);
  * attention output, to_out and the feed-forward for one row per frame (K/V for all) -- identical results, fewer
  * FLOPs.  0 switches this off (dense last block, for A/B measurements). */
 void dgvit_set_prune_last_layer(int on);
+/* Opt-in (default 0): dgvit_got_backward runs the weight-gradient GEMMs on one internal helper stream (created on
+ * first use, ordered against the caller's stream with events only, so it is capturable) to overlap them with the
+ * data-gradient chain: +5 % frames/s at C3 on MI355X, but concurrent kernels stretch each other's durations, so
+ * per-kernel timings (dgvit_profile_*, rocprof) stop being interpretable.  0 keeps everything on the caller's stream. */
+void dgvit_set_wgrad_overlap(int on);
 
 /* nn.LayerNorm(D), eps 1e-5 (GoalFormer.py:34,37): y, and the per-row mean / rstd saved for backward */
 int dgvit_layernorm_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

@@ -233,3 +233,30 @@ def test_last_block_token0_schedule_equals_dense(amd):
     for k in gd:
         scale = max(gd[k].abs().max().item(), 1e-8)
         assert (gd[k] - gp_[k]).abs().max().item() <= 2e-4 * scale + 1e-9, k
+
+
+def test_wgrad_helper_stream_equals_single_stream(amd):
+    """Opt-in overlap of weight-gradient GEMMs on the helper stream must not change any gradient (ordering is
+    event based); run twice to exercise event-ring reuse."""
+    lib = amd.load_library()
+    cfg = O.GoTConfig(image=(84, 84), patch=(12, 12), dim=256, depth=3, heads=8)
+    m = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, image_size=cfg.image, patch_size=cfg.patch),
+                    O.make_params(O.policy_param_spec(cfg), 41)).eval().to("cuda")
+    img, pstate, _, _ = (t.cuda() for t in O.make_inputs(cfg, 96, 41))
+
+    def run():
+        m.zero_grad()
+        mean, log_std = m([img, pstate])
+        ((mean ** 2).mean() + (log_std ** 2).mean()).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    ref = run()
+    try:
+        lib.dgvit_set_wgrad_overlap(1)
+        for _ in range(3):
+            got = run()
+            for k in ref:
+                assert torch.equal(ref[k], got[k]), k   # same kernels, same order of summation: bit identical
+    finally:
+        lib.dgvit_set_wgrad_overlap(0)
