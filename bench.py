@@ -109,7 +109,8 @@ def main():
     model = dgvit_amd.GoTPolicy(2, 2, DEPTH, HEADS, DIM, image_size=IMAGE, patch_size=PATCH).to(dev).train()
     sync = GradSync([model])
     sync.broadcast_parameters(0)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, foreach=True)
+    from dgvit_amd.optim import FlatAdam
+    opt = FlatAdam([model], lr=1e-4)            # torch.optim.Adam semantics, one HIP kernel per flat block
     img, pstate, _, _ = (t.to(dev) for t in O.make_inputs(cfg, B, 3407 + rank))   # rank-local frames, resident in HBM
     g = torch.Generator(device="cpu").manual_seed(rank)
     tgt_mean, tgt_ls = torch.randn(B, 2, generator=g).to(dev), torch.randn(B, 2, generator=g).to(dev)
@@ -168,7 +169,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C3: GoTPolicy DGViT-small (84x84@12x12, L6 H8 D256 M2048, N=50 tokens) actor fwd+bwd, "
-                                   "train mode (emb dropout 0.1), MSE-to-random-target loss, grad all-reduce + Adam step",
+                                   "train mode (emb dropout 0.1), MSE-to-random-target loss, grad all-reduce + Adam step (fused flat-buffer HIP Adam)",
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "gflop_per_frame_fwd_bwd": round(3 * fwd / 1e9, 4),
                        "last_block": "dense" if args.dense_last_block else "token-0 rows only (identical results; FLOPs counted dense)",

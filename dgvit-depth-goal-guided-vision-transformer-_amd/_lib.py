@@ -55,6 +55,8 @@ SIGNATURES = {
     "dgvit_attention_backward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dgvit_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dgvit_dropout": (_I, [_P, _LL, _ULL, _F, _P]),
+    "dgvit_adam_step": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _F, _LL, _P]),
+    "dgvit_soft_update": (_I, [_P, _P, _LL, _F, _P]),
     "dgvit_profile_start": (_I, [_I]),
     "dgvit_profile_stop": (_I, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_longlong)]),
 }

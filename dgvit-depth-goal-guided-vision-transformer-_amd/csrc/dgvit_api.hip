@@ -23,6 +23,8 @@ int patchify(const float*, float*, int, int, int, int, int, hipStream_t);
 int goal_row(const float*, const float*, float*, int, int, int, hipStream_t);
 int dropout_inplace(float*, long long, unsigned long long, float, hipStream_t);
 int relu_bwd(const float*, const float*, float*, long long, hipStream_t);
+int adam_step(float*, const float*, float*, float*, long long, float, float, float, float, float, long long, hipStream_t);
+int soft_update(float*, const float*, long long, float, hipStream_t);
 extern int g_gemm_tile_hint;
 static int g_prune_last = 1;  // last block: only token 0 feeds the output (GoalFormer.py:167)
 static int g_overlap_wgrad = 0;  // opt-in: run weight-gradient GEMMs on a helper stream beside the data-gradient chain
@@ -544,4 +546,13 @@ extern "C" int dgvit_patchify(const float* img, float* patches, int B, int ih, i
 }
 extern "C" int dgvit_dropout(float* x, long long n, unsigned long long seed, float keep, void* stream) {
   return dropout_inplace(x, n, seed, keep, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------- optimiser step
+extern "C" int dgvit_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, long long step, void* stream) {
+  return adam_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+}
+extern "C" int dgvit_soft_update(float* target, const float* source, long long n, float tau, void* stream) {
+  return soft_update(target, source, n, tau, (hipStream_t)stream);
 }

@@ -154,6 +154,17 @@ int dgvit_patchify(const float* img, float* patches, int B, int image_h, int ima
 int dgvit_dropout(float* x, long long n, unsigned long long seed, float keep, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * The step after the path: torch.optim.Adam.step over all tensors of a network
+ * (DRL.py:401-403,412-414) and the Polyak target update target = target*(1-tau) + source*tau (utils.py:31-33),
+ * each as ONE pass over flat fp32 buffers (n multiple of 4, 16-byte aligned; see dgvit_amd.optim).
+ * Adam follows torch.optim.Adam: m,v updates, bias corrections with `step` (1-based), eps added to sqrt(v_hat),
+ * weight_decay as L2 term added to the gradient.
+ * -------------------------------------------------------------------------------------------- */
+int dgvit_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, long long step, void* stream);
+int dgvit_soft_update(float* target, const float* source, long long n, float tau, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Optional live kernel timing (HIP events on the launch stream around every kernel launch).
  * kinds: 0 GEMM (work = 2*M*N*K FLOPs), 1 attention fwd, 2 attention bwd (work = algorithmic FLOPs),
  *        3 normalisation / reductions / elementwise (work = 0).

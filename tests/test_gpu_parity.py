@@ -260,3 +260,44 @@ def test_wgrad_helper_stream_equals_single_stream(amd):
                 assert torch.equal(ref[k], got[k]), k   # same kernels, same order of summation: bit identical
     finally:
         lib.dgvit_set_wgrad_overlap(0)
+
+
+def test_flat_adam_matches_torch_adam(amd):
+    """dgvit_adam_step over flat buffers == torch.optim.Adam (DRL.py:126-168 uses it) for three steps, including the
+    zero-copy pickup of the fused backward's flat gradient buffer and parameters without gradients."""
+    import copy
+    from dgvit_amd.optim import FlatAdam
+    cfg = O.GoTConfig(image=(84, 84), patch=(12, 12), dim=64, depth=2, heads=2)
+    params = O.make_params(O.policy_param_spec(cfg), 51)
+    kw = dict(image_size=cfg.image, patch_size=cfg.patch)
+    a = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, **kw), params).eval().to("cuda")
+    b = copy.deepcopy(a)
+    oa = FlatAdam([a], lr=3e-3, weight_decay=0.01)
+    ob = torch.optim.Adam(b.parameters(), lr=3e-3, weight_decay=0.01)
+    img, pstate, _, _ = (t.cuda() for t in O.make_inputs(cfg, 16, 51))
+    for it in range(3):
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad(set_to_none=True)
+            mean, log_std = m([img, pstate])
+            ((mean ** 2).mean() + (log_std ** 2).mean() * (it + 1)).backward()
+            o.step()
+    blk = oa.blocks[0]
+    assert blk.gflat is None, "encoder gradients should have been consumed in place (zero copy)"
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+    assert torch.equal(a.trans.cls_token, b.trans.cls_token)     # never gets a gradient: untouched by both
+
+
+def test_soft_update_flat(amd):
+    from dgvit_amd.optim import flatten_parameters, soft_update
+    torch.manual_seed(0)
+    src = amd.GoTQNetwork(2, 2, 1, 2, 64).to("cuda")
+    tgt = amd.GoTQNetwork(2, 2, 1, 2, 64).to("cuda")
+    want = [t.detach().clone() * (1 - 0.005) + s.detach() * 0.005 for t, s in zip(tgt.parameters(), src.parameters())]
+    flatten_parameters(src)
+    flatten_parameters(tgt)
+    soft_update(tgt, src, 0.005)
+    for w, t in zip(want, tgt.parameters()):
+        np.testing.assert_allclose(t.detach().cpu().numpy(), w.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    q1, _ = tgt([torch.rand(2, 128, 160, device="cuda"), torch.rand(2, 2, device="cuda"), torch.rand(2, 2, device="cuda")])
+    assert torch.isfinite(q1).all()                     # the re-homed parameters still drive the HIP forward
