@@ -18,6 +18,9 @@
 namespace {
 
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// softmax runs in base 2: the query is pre-scaled by scale*log2(e), so exp(x - max) = exp2(s' - max') on v_exp_f32
+#define DGVIT_LOG2E 1.4426950408889634f
+#define DGVIT_LN2 0.6931471805599453f
 
 // stage rows [0, N) of one head's 64-wide (DH-wide) column block into LDS image [NP][SK], zero padding rows
 template <int DH, int SK>
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
   for (int qt = wave; qt < nqt; qt += nw) {
     const int q = qt * 32 + li;
     float4 qf[DH / 8];
-    row_frags<DH>(qf, base + q * ld, q < nq, h, scale);
+    row_frags<DH>(qf, base + q * ld, q < nq, h, scale * DGVIT_LOG2E);
 
     f32x16 s[NKT];
 #pragma unroll
@@ -116,7 +119,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = expf(s[kt][r] - m);
+        const float p = __builtin_amdgcn_exp2f(s[kt][r] - m);
         s[kt][r] = p;
         l += p;
       }
@@ -170,7 +173,7 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__
     const int q = qt * 32 + li;
     const bool qv = q < nq;
     float4 qf[DH / 8], dof[DH / 8], of[DH / 8];
-    row_frags<DH>(qf, base + q * ld, qv, h, scale);
+    row_frags<DH>(qf, base + q * ld, qv, h, scale * DGVIT_LOG2E);
     row_frags<DH>(dof, dobase + (long long)q * I, qv, h, 1.f);
     row_frags<DH>(of, obase + (long long)q * I, qv, h, 1.f);
     float delta = 0.f;
@@ -201,14 +204,14 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = expf(p[kt][r] - m);
+        const float e = __builtin_amdgcn_exp2f(p[kt][r] - m);
         p[kt][r] = e;
         l += e;
       }
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.f / l;
     if (h == 0) {
-      lse_s[q] = m + logf(l);
+      lse_s[q] = m + __builtin_amdgcn_logf(l);   // base-2 log-sum-exp of the base-2 scores
       del_s[q] = delta;
     }
 
@@ -266,7 +269,7 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int q = qt * 32 + acc_row(r, h);
-        const float pv = (kv && q < nq) ? expf(s[r] * scale - lse_s[q]) : 0.f;
+        const float pv = (kv && q < nq) ? __builtin_amdgcn_exp2f(s[r] * (scale * DGVIT_LOG2E) - lse_s[q]) : 0.f;
         const float ds = pv * (dp[r] - del_s[q]) * scale;
         const float* dorow = Y + q * SK + li;
         const float* qrow = X + q * SK + li;
