@@ -87,13 +87,19 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a ROCm GPU", file=sys.stderr)
         sys.exit(2)
+    if os.environ.get("DGVIT_BENCH_SHARE_GPU") == "1":   # rehearsal only: several ranks on one card
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("DGVIT_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse several ranks on one card
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import dgvit_amd
     from dgvit_amd.parallel import GradSync

@@ -420,29 +420,41 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(const GemmParams p) {
   }
 }
 
-// out1[0..n1) , out2[0..n-n1)  <-  sum over slabs of slab[z][0..n)   (fixed order -> deterministic)
+// out1[0..n1) , out2[0..n-n1)  <-  sum over slabs of slab[z][0..n)
+// 256 threads = 64 float4 columns x 4 slab groups: group y sums slabs y, y+4, y+8, ... (4 loads in flight each),
+// then the four partial sums are combined through LDS in the fixed order ((g0+g1)+(g2+g3)): deterministic.
 __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out1,
                                                            float* __restrict__ out2, long long n4, long long n14, int nslab,
                                                            long long stride) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  const float4* src = reinterpret_cast<const float4*>(slabs) + i;
-  const long long st4 = stride / 4;
+  __shared__ float4 part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + tx;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  int z = 0;
-  for (; z + 4 <= nslab; z += 4) {
-    const float4 a = src[(z + 0) * st4], b = src[(z + 1) * st4], c = src[(z + 2) * st4], d = src[(z + 3) * st4];
-    s.x += (a.x + b.x) + (c.x + d.x);
-    s.y += (a.y + b.y) + (c.y + d.y);
-    s.z += (a.z + b.z) + (c.z + d.z);
-    s.w += (a.w + b.w) + (c.w + d.w);
+  if (i < n4) {
+    const float4* src = reinterpret_cast<const float4*>(slabs) + i;
+    const long long st4 = stride / 4;
+    int z = ty;
+    for (; z + 12 < nslab; z += 16) {
+      const float4 a = src[(z + 0) * st4], b = src[(z + 4) * st4], c = src[(z + 8) * st4], d = src[(z + 12) * st4];
+      s.x += (a.x + b.x) + (c.x + d.x);
+      s.y += (a.y + b.y) + (c.y + d.y);
+      s.z += (a.z + b.z) + (c.z + d.z);
+      s.w += (a.w + b.w) + (c.w + d.w);
+    }
+    for (; z < nslab; z += 4) {
+      const float4 a = src[z * st4];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
   }
-  for (; z < nslab; ++z) {
-    const float4 a = src[z * st4];
-    s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < n4) {
+    const float4 a = part[0][tx], b = part[1][tx], c = part[2][tx], d = part[3][tx];
+    const float4 r = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
+                                 (a.w + b.w) + (c.w + d.w));
+    if (i < n14) reinterpret_cast<float4*>(out1)[i] = r;
+    else reinterpret_cast<float4*>(out2)[i - n14] = r;
   }
-  if (i < n14) reinterpret_cast<float4*>(out1)[i] = s;
-  else reinterpret_cast<float4*>(out2)[i - n14] = s;
 }
 
 __global__ void __launch_bounds__(256) reduce_slabs_scalar_kernel(const float* __restrict__ slabs, float* __restrict__ out1,
@@ -550,7 +562,7 @@ int reduce_slabs2(const float* slabs, float* out1, long long n1, float* out2, lo
   const int slot = profile_begin(PROF_OTHER, 0.0, stream);
   if (n % 4 == 0 && n1 % 4 == 0 && slab_stride % 4 == 0 && al16(slabs) && al16(out1) && (n1 == n || al16(out2))) {
     const long long n4 = n / 4;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, slabs, out1, out2, n4, n1 / 4,
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, stream, slabs, out1, out2, n4, n1 / 4,
                        nslab, slab_stride);
   } else {
     hipLaunchKernelGGL(reduce_slabs_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slabs, out1, out2, n, n1,
