@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--no-sac-step", action="store_true", help="skip the secondary full SAC-style step measurement")
     ap.add_argument("--wgrad-overlap", action="store_true", help="A/B: weight-gradient GEMMs on the helper stream (+5%% frames/s, blurs per-kernel timing)")
     ap.add_argument("--dense-last-block", action="store_true", help="A/B: compute the last block for every token")
     return ap.parse_args()
@@ -72,6 +73,51 @@ def cpu_baseline(batch):
     return {"value": round(batch / best, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle/dgvit_oracle.py policy fwd+bwd on {batch} of the 512 frames, train-mode mask, best of 3, "
                       f"{torch.get_num_threads()} torch threads"}
+
+
+def sac_step(dgvit_amd, O, cfg, B, dev, steps=5):
+    """Secondary number (SURVEY 8(d) C3 "secondary"): one SAC-style update with transformer actor AND transformer
+    critic, losses as DRL.py:390-432 (alpha fixed 0.2, gamma 0.99): 2 no-grad target passes, critic fwd+bwd,
+    actor fwd + critic fwd + bwd through both, two Adam steps, Polyak update.  5 encoder forwards and 3 encoder
+    backwards per frame."""
+    from dgvit_amd.optim import FlatAdam, flatten_parameters, soft_update
+    import copy
+    torch.manual_seed(1)
+    kw = dict(image_size=IMAGE, patch_size=PATCH)
+    pol = dgvit_amd.GoTPolicy(2, 2, DEPTH, HEADS, DIM, **kw).to(dev)
+    crt = dgvit_amd.GoTQNetwork(2, 2, DEPTH, HEADS, DIM, **kw).to(dev)
+    tgt = copy.deepcopy(crt)
+    flatten_parameters(crt), flatten_parameters(tgt)
+    opt_p, opt_c = FlatAdam([pol], lr=1e-4), FlatAdam([crt], lr=1e-4)
+    img, pstate, act, _ = (t.to(dev) for t in O.make_inputs(cfg, B, 11))
+    nimg, npst, _, _ = (t.to(dev) for t in O.make_inputs(cfg, B, 12))
+    rew = torch.randn(B, 1, device=dev)
+    alpha, gamma, tau = 0.2, 0.99, 0.005
+
+    def step():
+        with torch.no_grad():
+            na, nlogp, _ = pol.sample([nimg, npst])
+            q1n, q2n = tgt([nimg, npst, na])
+            y = rew + gamma * (torch.min(q1n, q2n) - alpha * nlogp)
+        q1, q2 = crt([img, pstate, act])
+        qf = torch.nn.functional.mse_loss(q1, y) + torch.nn.functional.mse_loss(q2, y)
+        opt_c.zero_grad(); qf.backward(); opt_c.step()
+        pi, logp, _ = pol.sample([img, pstate])
+        q1p, q2p = crt([img, pstate, pi])
+        pl = (alpha * logp - torch.min(q1p, q2p)).mean()
+        opt_p.zero_grad(); opt_c.zero_grad(); pl.backward(); opt_p.step()
+        soft_update(tgt, crt, tau)
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(B / dt, 1), "encoder_passes": "5 fwd + 3 bwd per frame",
+            "note": "transformer actor + transformer critic, DRL.py:390-432 arithmetic"}
 
 
 def main():
@@ -191,6 +237,8 @@ def main():
                            "gemm_ms_per_step": round(ms[0] / args.steps, 3), "attn_fwd_ms_per_step": round(ms[1] / args.steps, 3),
                            "attn_bwd_ms_per_step": round(ms[2] / args.steps, 3), "final_loss": round(final_loss, 5)},
         }
+        if world == 1 and not args.no_sac_step:
+            out["sac_step"] = sac_step(dgvit_amd, O, cfg, B, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(out), flush=True)

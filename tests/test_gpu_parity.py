@@ -301,3 +301,70 @@ def test_soft_update_flat(amd):
         np.testing.assert_allclose(t.detach().cpu().numpy(), w.cpu().numpy(), rtol=1e-6, atol=1e-7)
     q1, _ = tgt([torch.rand(2, 128, 160, device="cuda"), torch.rand(2, 2, device="cuda"), torch.rand(2, 2, device="cuda")])
     assert torch.isfinite(q1).all()                     # the re-homed parameters still drive the HIP forward
+
+
+def test_large_batch_indexing(amd):
+    """B = 2048 frames (T = 102400 token rows, > 2^31 bytes of hidden activations): 64-bit indexing everywhere.
+    Frame independence: rows of the big batch equal the same frames run as a small batch."""
+    cfg = O.GoTConfig(image=(84, 84), patch=(12, 12), dim=256, depth=2, heads=8)
+    torch.manual_seed(3)
+    m = amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, image_size=cfg.image, patch_size=cfg.patch).to("cuda").eval()
+    img, pstate, _, _ = (t.cuda() for t in O.make_inputs(cfg, 2048, 9))
+    mean, log_std = m([img, pstate])
+    ((mean ** 2).mean() + (log_std ** 2).mean()).backward()
+    g_big = m.trans.transformer.layers[1][1].fn.net[0].weight.grad.clone()
+    assert torch.isfinite(g_big).all() and torch.isfinite(mean).all()
+    with torch.no_grad():
+        ms, _ = m([img[2040:2048], pstate[2040:2048]])
+    np.testing.assert_allclose(ms.cpu().numpy(), mean[2040:2048].detach().cpu().numpy(), rtol=0, atol=2e-5)
+    # gradient of the mean loss over 2048 frames == mean of the gradients of its four 512-frame quarters
+    acc = torch.zeros_like(g_big)
+    for q in range(4):
+        m.zero_grad()
+        a, b = m([img[q * 512:(q + 1) * 512], pstate[q * 512:(q + 1) * 512]])
+        ((a ** 2).mean() + (b ** 2).mean()).backward()
+        acc += m.trans.transformer.layers[1][1].fn.net[0].weight.grad / 4
+    assert (acc - g_big).abs().max().item() <= 2e-3 * g_big.abs().max().item() + 1e-8
+
+
+def test_choose_action_and_sample(amd):
+    """GoTPolicy.choose_action (got_sac_network.py:205-220): numpy (H, W, 1) frame + (2,) goal -> numpy (2,) action."""
+    cfg = O.GoTConfig(dim=64, depth=4, heads=4)
+    params = O.make_params(O.policy_param_spec(cfg), 3407)
+    m = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim), params).eval().to("cuda")
+    img, pstate, _, _ = O.make_inputs(cfg, 1, 3407)
+    frame = img[0].numpy()[:, :, None]                     # (128, 160, 1) as env_lab hands it over
+    act_eval = m.choose_action(frame, pstate[0].numpy(), evaluate=True)
+    rm, _ = O.policy_forward(params, img, pstate, cfg)
+    assert act_eval.shape == (2,)
+    np.testing.assert_allclose(act_eval, torch.tanh(rm)[0].numpy(), rtol=0, atol=OUT_TOL)
+    act = m.choose_action(frame, pstate[0].numpy(), evaluate=False)
+    assert act.shape == (2,) and np.all(np.abs(act) <= 1.0)
+    a, logp, mean = m.sample([img.cuda(), pstate.cuda()])
+    assert a.shape == (1, 2) and logp.shape == (1, 1) and torch.isfinite(logp).all()
+
+
+def test_c_abi_error_codes(amd):
+    """Workspace too small / null pointers / bad config come back as negative codes with a message, no crash."""
+    import ctypes
+    from dgvit_amd._lib import dgvit_config
+    lib = amd.load_library()
+    cfg = dgvit_config(84, 84, 12, 12, 64, 1, 2, 64, 2048)
+    n = lib.dgvit_got_workspace_floats(ctypes.byref(cfg), 2, 1)
+    ws = torch.empty(n, device="cuda")
+    img, goal, feat = torch.rand(2, 84, 84, device="cuda"), torch.rand(2, 64, device="cuda"), torch.empty(2, 64, device="cuda")
+    m = amd.GoT(image_size=(84, 84), patch_size=(12, 12), num_classes=2, dim=64, depth=1, heads=2, mlp_dim=2048).to("cuda")
+    tbl = (ctypes.c_void_p * 15)(*[p.data_ptr() for p in m.param_table()])
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.dgvit_got_forward(ctypes.byref(cfg), tbl, P(img), P(goal), P(feat), P(ws), n - 1, 2, 1, 1.0, 0, st) == -4
+    assert b"workspace" in lib.dgvit_last_error()
+    assert lib.dgvit_got_forward(ctypes.byref(cfg), tbl, None, P(goal), P(feat), P(ws), n, 2, 1, 1.0, 0, st) == -1
+    assert lib.dgvit_got_forward(ctypes.byref(cfg), tbl, P(img), P(goal), P(feat), P(ws), n, 2, 1, 1.5, 0, st) == -1
+    assert lib.dgvit_got_forward(ctypes.byref(cfg), tbl, P(img), P(goal), P(feat), P(ws), n, 2, 1, 1.0, 0, st) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(feat).all()
+    with pytest.raises(amd.DgvitError, match="img must be"):
+        m(torch.rand(2, 80, 84, device="cuda"), goal)
+    with pytest.raises(amd.DgvitError, match="fp32"):
+        m(img.double(), goal)
