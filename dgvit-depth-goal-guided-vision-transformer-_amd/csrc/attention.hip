@@ -22,26 +22,49 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 #define DGVIT_LOG2E 1.4426950408889634f
 #define DGVIT_LN2 0.6931471805599453f
 
-// stage rows [0, N) of one head's 64-wide (DH-wide) column block into LDS image [NP][SK], zero padding rows
-template <int DH, int SK>
-__device__ __forceinline__ void stage_rows(float* dst, const float* src, long long ld, int N, int NP, int tid, int nthr) {
+// Stage rows [0, nrows) of two 64-wide (DH-wide) per-head column blocks into LDS images [NP][SK], zero padding
+// rows.  Fully unrolled for the compile-time thread count: every thread first issues ALL its global loads
+// (2 * NP*DH/4/NTHR float4 in flight), then writes LDS -- a runtime-trip-count loop here serialises one memory
+// round trip per float4.  Out-of-range rows read row 0 and are zeroed by a select (no divergent branches).
+template <int DH, int SK, int NP, int NTHR>
+__device__ __forceinline__ void stage_pair(float* dstA, const float* srcA, long long ldA, float* dstB, const float* srcB,
+                                           long long ldB, int nrows, int tid) {
   constexpr int C4 = DH / 4;
-  for (int f = tid; f < NP * C4; f += nthr) {
-    const int row = f / C4, c = (f % C4) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < N) v = *reinterpret_cast<const float4*>(src + row * ld + c);
-    *reinterpret_cast<float4*>(dst + row * SK + c) = v;
+  constexpr int ITER = (NP * C4 + NTHR - 1) / NTHR;
+  constexpr int CH = 4;   // 2*CH float4 (32 VGPRs) in flight per thread: enough to cover the latency, no spills
+#pragma unroll
+  for (int i0 = 0; i0 < ITER; i0 += CH) {
+    float4 va[CH], vb[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int f = tid + (i0 + j) * NTHR;
+      const int row = f / C4, c = (f % C4) * 4;
+      const int rr = (i0 + j < ITER && row < nrows) ? row : 0;
+      va[j] = *reinterpret_cast<const float4*>(srcA + rr * ldA + c);
+      vb[j] = *reinterpret_cast<const float4*>(srcB + rr * ldB + c);
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int f = tid + (i0 + j) * NTHR;
+      const int row = f / C4, c = (f % C4) * 4;
+      if (i0 + j < ITER && (NP * C4 % NTHR == 0 || row < NP)) {
+        const float k = row < nrows ? 1.f : 0.f;   // (a float4 ?: would be lowered through scratch memory)
+        *reinterpret_cast<float4*>(dstA + row * SK + c) = make_float4(va[j].x * k, va[j].y * k, va[j].z * k, va[j].w * k);
+        *reinterpret_cast<float4*>(dstB + row * SK + c) = make_float4(vb[j].x * k, vb[j].y * k, vb[j].z * k, vb[j].w * k);
+      }
+    }
   }
 }
 
-// B-operand style fragments of row `q` (lane owns a row): elements [8g + 4h .. +3], g = 0..DH/8
+// B-operand style fragments of one row (lane owns a row): elements [8g + 4h .. +3], g = 0..DH/8.
+// `rowptr` must point at a readable row (callers clamp the row index); invalid rows are zeroed by a select.
 template <int DH>
 __device__ __forceinline__ void row_frags(float4 (&f)[DH / 8], const float* rowptr, bool valid, int h, float mul) {
+  const float m = valid ? mul : 0.f;
 #pragma unroll
   for (int g = 0; g < DH / 8; ++g) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid) v = *reinterpret_cast<const float4*>(rowptr + 8 * g + 4 * h);
-    f[g] = make_float4(v.x * mul, v.y * mul, v.z * mul, v.w * mul);
+    const float4 v = *reinterpret_cast<const float4*>(rowptr + 8 * g + 4 * h);
+    f[g] = make_float4(v.x * m, v.y * m, v.z * m, v.w * m);
   }
 }
 
@@ -74,28 +97,32 @@ __device__ __forceinline__ void store_T(const f32x16 (&o)[DH / 32], float* rowpt
 
 // ------------------------------------------------------------------------------------ forward
 template <int DH, int NKT>
-__global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int H,
+__global__ void __launch_bounds__(64 * (NKT < 4 ? NKT : 4), NKT <= 2 ? 2 : 1) attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int H,
                                                        float scale, int nq) {
   constexpr int SK = DH + 4, NP = NKT * 32, DT = DH / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;
   float* Vs = smem + NP * SK;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  constexpr int NW = NKT < 4 ? NKT : 4, NTHR = 64 * NW;   // launch configuration (see launch_fwd)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = NW;
   const int li = lane & 31, h = lane >> 5;
   const int b = blockIdx.x / H, hd = blockIdx.x % H;
   const int I = H * DH;
   const long long ld = 3ll * I;
   const float* base = qkv + (long long)b * N * ld + hd * DH;
 
-  stage_rows<DH, SK>(Ks, base + I, ld, N, NP, tid, blockDim.x);
-  stage_rows<DH, SK>(Vs, base + 2 * I, ld, N, NP, tid, blockDim.x);
+  const int nqt = (nq + 31) / 32;   // only queries < nq are needed (nq = 1: the last block keeps token 0 only)
+  // the per-lane Q fragments are requested BEFORE the K/V staging so both global round trips overlap
+  float4 qf[DH / 8];
+  {
+    const int q0 = wave * 32 + li;
+    row_frags<DH>(qf, base + (q0 < nq ? q0 : 0) * ld, q0 < nq, h, scale * DGVIT_LOG2E);
+  }
+  stage_pair<DH, SK, NP, NTHR>(Ks, base + I, ld, Vs, base + 2 * I, ld, N, tid);
   __syncthreads();
 
-  const int nqt = (nq + 31) / 32;   // only queries < nq are needed (nq = 1: the last block keeps token 0 only)
   for (int qt = wave; qt < nqt; qt += nw) {
     const int q = qt * 32 + li;
-    float4 qf[DH / 8];
-    row_frags<DH>(qf, base + q * ld, q < nq, h, scale * DGVIT_LOG2E);
 
     f32x16 s[NKT];
 #pragma unroll
@@ -103,6 +130,11 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
       mfma_rows_x_frags<DH, SK>(s[kt], Ks, kt * 32 + li, h, qf);
+    }
+    if (qt + nw < nqt)   // next tile's Q fragments travel while this tile's softmax and P.V run
+    {
+      const int qn = (qt + nw) * 32 + li;
+      row_frags<DH>(qf, base + (qn < nq ? qn : 0) * ld, qn < nq, h, scale * DGVIT_LOG2E);
     }
     float m = -INFINITY;
 #pragma unroll
@@ -144,7 +176,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------------------------ backward
 template <int DH, int NKT>
-__global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o_fwd,
+__global__ void __launch_bounds__(64 * (NKT < 4 ? NKT : 4), NKT <= 2 ? 2 : 1) attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o_fwd,
                                                        const float* __restrict__ d_out, float* __restrict__ dqkv, int N, int H,
                                                        float scale, int nq) {
   constexpr int SK = DH + 4, NP = NKT * 32, DT = DH / 32;
@@ -153,7 +185,8 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__
   float* Y = smem + NP * SK;       // phase 1: V      phase 2: dO
   float* lse_s = smem + 2 * NP * SK;
   float* del_s = lse_s + NP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  constexpr int NW = NKT < 4 ? NKT : 4, NTHR = 64 * NW;   // launch configuration (see launch_bwd)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = NW;
   const int li = lane & 31, h = lane >> 5;
   const int b = blockIdx.x / H, hd = blockIdx.x % H;
   const int I = H * DH;
@@ -163,19 +196,29 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__
   const float* dobase = d_out + (long long)b * N * I + hd * DH;
   float* gbase = dqkv + (long long)b * N * ld + hd * DH;
 
-  stage_rows<DH, SK>(X, base + I, ld, N, NP, tid, blockDim.x);
-  stage_rows<DH, SK>(Y, base + 2 * I, ld, N, NP, tid, blockDim.x);
+  const int nqt = (nq + 31) / 32;
+  float4 qf[DH / 8], dof[DH / 8], of[DH / 8];
+  {  // first query tile's per-lane fragments are requested before the K/V staging (overlapping round trips)
+    const int q0 = wave * 32 + li;
+    const bool v0 = q0 < nq;
+    const int qc = v0 ? q0 : 0;
+    row_frags<DH>(qf, base + qc * ld, v0, h, scale * DGVIT_LOG2E);
+    row_frags<DH>(dof, dobase + (long long)qc * I, v0, h, 1.f);
+    row_frags<DH>(of, obase + (long long)qc * I, v0, h, 1.f);
+  }
+  stage_pair<DH, SK, NP, NTHR>(X, base + I, ld, Y, base + 2 * I, ld, N, tid);
   __syncthreads();
 
   // ---- phase 1: one query tile per wave -> dQ, lse, delta
-  const int nqt = (nq + 31) / 32;
   for (int qt = wave; qt < nqt; qt += nw) {
     const int q = qt * 32 + li;
     const bool qv = q < nq;
-    float4 qf[DH / 8], dof[DH / 8], of[DH / 8];
-    row_frags<DH>(qf, base + q * ld, qv, h, scale * DGVIT_LOG2E);
-    row_frags<DH>(dof, dobase + (long long)q * I, qv, h, 1.f);
-    row_frags<DH>(of, obase + (long long)q * I, qv, h, 1.f);
+    if (qt != wave) {
+      const int qc = qv ? q : 0;
+      row_frags<DH>(qf, base + qc * ld, qv, h, scale * DGVIT_LOG2E);
+      row_frags<DH>(dof, dobase + (long long)qc * I, qv, h, 1.f);
+      row_frags<DH>(of, obase + (long long)qc * I, qv, h, 1.f);
+    }
     float delta = 0.f;
 #pragma unroll
     for (int g = 0; g < DH / 8; ++g)
@@ -236,18 +279,26 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const float* __restrict__
     }
     if (qv) store_T<DH>(dq, gbase + q * ld, h, 1.f);
   }
-  __syncthreads();
-
   // ---- phase 2: Q and dO into LDS, one key tile per wave -> dK, dV
-  stage_rows<DH, SK>(X, base, ld, nq, NP, tid, blockDim.x);      // rows >= nq are zero-filled: they carry no gradient
-  stage_rows<DH, SK>(Y, dobase, I, nq, NP, tid, blockDim.x);
+  float4 kf[DH / 8], vf[DH / 8];
+  {  // first key tile's fragments are requested before the phase barrier and the restaging
+    const int k0 = wave * 32 + li;
+    const bool v0 = k0 < N;
+    const int kc = v0 ? k0 : 0;
+    row_frags<DH>(kf, base + I + kc * ld, v0, h, 1.f);
+    row_frags<DH>(vf, base + 2 * I + kc * ld, v0, h, 1.f);
+  }
+  __syncthreads();
+  stage_pair<DH, SK, NP, NTHR>(X, base, ld, Y, dobase, (long long)I, nq, tid);   // rows >= nq zero-filled: no gradient
   __syncthreads();
   for (int kt = wave; kt < NKT; kt += nw) {
     const int key = kt * 32 + li;
     const bool kv = key < N;
-    float4 kf[DH / 8], vf[DH / 8];
-    row_frags<DH>(kf, base + I + key * ld, kv, h, 1.f);
-    row_frags<DH>(vf, base + 2 * I + key * ld, kv, h, 1.f);
+    if (kt != wave) {
+      const int kc = kv ? key : 0;
+      row_frags<DH>(kf, base + I + kc * ld, kv, h, 1.f);
+      row_frags<DH>(vf, base + 2 * I + kc * ld, kv, h, 1.f);
+    }
     f32x16 dk[DT], dv[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
