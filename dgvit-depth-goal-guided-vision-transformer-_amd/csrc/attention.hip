@@ -68,8 +68,6 @@ __device__ __forceinline__ void row_frags(float4 (&f)[DH / 8], const float* rowp
   }
 }
 
-__device__ __forceinline__ float f4get(const float4& v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
-
 // acc += rowsA(LDS image, rows base+li) . fragsB   over the DH-deep contraction
 template <int DH, int SK>
 __device__ __forceinline__ void mfma_rows_x_frags(f32x16& acc, const float* img, int row, int h, const float4 (&fb)[DH / 8]) {

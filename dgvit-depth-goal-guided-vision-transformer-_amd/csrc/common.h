@@ -8,8 +8,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define DGVIT_WAVE 64
-
 // ---- error reporting (thread-local message, negative return codes from include/dgvit_hip.h) ------
 int dgvit_set_error(int code, const char* fmt, ...);
 

@@ -121,7 +121,9 @@ class GoTPolicy(nn.Module):
     def sample(self, inp):
         mean, log_std = self.forward(inp)
         std = log_std.exp()
-        normal = Normal(mean, std)
+        # validate_args=False: the default argument check is a device->host sync on every call (and cannot be
+        # captured into a HIP graph); the arithmetic is the reference's (got_sac_network.py:240-250)
+        normal = Normal(mean, std, validate_args=False)
         x_t = normal.rsample()
         y_t = torch.tanh(x_t)
         action = y_t * self.action_scale + self.action_bias
