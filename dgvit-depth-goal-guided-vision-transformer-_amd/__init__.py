@@ -6,7 +6,8 @@ touches the GPU; the first call loads the library and raises ``DgvitError`` if i
 from ._lib import DgvitError, LIB_PATH, load as load_library  # noqa: F401
 from .goalformer import GoT  # noqa: F401
 from .sac_networks import GoTPolicy, GoTQNetwork, DeterministicGoTPolicy, weights_init_  # noqa: F401
+from .cnn_networks import QNetwork, GaussianPolicy  # noqa: F401
 from . import functional  # noqa: F401
 
-__all__ = ["GoT", "GoTPolicy", "GoTQNetwork", "DeterministicGoTPolicy", "weights_init_", "functional", "DgvitError",
+__all__ = ["GoT", "GoTPolicy", "GoTQNetwork", "DeterministicGoTPolicy", "QNetwork", "GaussianPolicy", "weights_init_", "functional", "DgvitError",
            "load_library", "LIB_PATH"]

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <algorithm>
 #include <mutex>
 
 #include "../../include/dgvit_hip.h"
@@ -25,6 +26,11 @@ int dropout_inplace(float*, long long, unsigned long long, float, hipStream_t);
 int relu_bwd(const float*, const float*, float*, long long, hipStream_t);
 int adam_step(float*, const float*, float*, float*, long long, float, float, float, float, float, long long, hipStream_t);
 int soft_update(float*, const float*, long long, float, hipStream_t);
+int im2col(const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+int col2im_relu(const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
+int weight_pack(const float*, float*, int, int, int, int, hipStream_t);
+int avgpool(const float*, float*, int, int, int, hipStream_t);
+int avgpool_bwd_relu(const float*, const float*, float*, int, int, int, hipStream_t);
 extern int g_gemm_tile_hint;
 static int g_prune_last = 1;  // last block: only token 0 feeds the output (GoalFormer.py:167)
 static int g_overlap_wgrad = 0;  // opt-in: run weight-gradient GEMMs on a helper stream beside the data-gradient chain
@@ -555,4 +561,116 @@ extern "C" int dgvit_adam_step(float* p, const float* g, float* m, float* v, lon
 }
 extern "C" int dgvit_soft_update(float* target, const float* source, long long n, float tau, void* stream) {
   return soft_update(target, source, n, tau, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------- CNN feature stack
+// (the shipped critic QNetwork and the CNN actor; got_sac_network.py:129-133,151-155)
+namespace {
+struct ConvDims {
+  int B, H[4], W[4], C[4], KP[3];   // layer l maps (H[l], W[l], C[l]) -> (H[l+1], W[l+1], C[l+1])
+  long long M[4];                   // rows of the NHWC activation l (M[0] unused)
+};
+int make_conv_dims(int B, int H, int W, ConvDims& d) {
+  DGVIT_CHECK_ARG(B > 0 && H >= 29 && W >= 29, "cnn: need batch > 0 and frames of at least 29x29");
+  d.B = B; d.H[0] = H; d.W[0] = W; d.C[0] = 1; d.C[1] = 16; d.C[2] = 64; d.C[3] = 256;
+  for (int l = 0; l < 3; ++l) {
+    d.H[l + 1] = (d.H[l] - 5) / 2 + 1;
+    d.W[l + 1] = (d.W[l] - 5) / 2 + 1;
+    d.KP[l] = l == 0 ? 28 : 25 * d.C[l];
+    d.M[l + 1] = (long long)B * d.H[l + 1] * d.W[l + 1];
+    DGVIT_CHECK_ARG(d.H[l + 1] > 0 && d.W[l + 1] > 0 && d.M[l + 1] < (1ll << 31), "cnn: frame too small or batch too large");
+  }
+  return DGVIT_OK;
+}
+long long conv_cols_floats(const ConvDims& d) {
+  long long m = 0;
+  for (int l = 0; l < 3; ++l) m = std::max(m, d.M[l + 1] * d.KP[l]);
+  return al4(m);
+}
+long long conv_wp_floats(const ConvDims& d) { return al4(16 * 28) + al4(64 * 400) + al4(256 * 1600); }
+}  // namespace
+
+extern "C" long long dgvit_cnn_workspace_floats(int B, int H, int W) {
+  ConvDims d;
+  if (make_conv_dims(B, H, W, d)) return -1;
+  return al4(d.M[1] * 16) + al4(d.M[2] * 64) + al4(d.M[3] * 256);
+}
+extern "C" long long dgvit_cnn_forward_scratch_floats(int B, int H, int W) {
+  ConvDims d;
+  if (make_conv_dims(B, H, W, d)) return -1;
+  return conv_cols_floats(d) + conv_wp_floats(d);
+}
+extern "C" long long dgvit_cnn_backward_scratch_floats(int B, int H, int W) {
+  ConvDims d;
+  if (make_conv_dims(B, H, W, d)) return -1;
+  long long dy = std::max(std::max(d.M[1] * 16, d.M[2] * 64), d.M[3] * 256);
+  long long slabs = std::max(std::max(wgrad_scratch(16, 28, (int)d.M[1]), wgrad_scratch(64, 400, (int)d.M[2])), wgrad_scratch(256, 1600, (int)d.M[3]));
+  return conv_cols_floats(d) + 2 * conv_wp_floats(d) + 2 * al4(dy) + slabs;
+}
+
+// params: conv1.weight (16,1,5,5), conv1.bias, conv2.weight (64,16,5,5), conv2.bias, conv3.weight (256,64,5,5), conv3.bias
+extern "C" int dgvit_cnn_forward(const float* img, const float* const* params, float* feat, float* ws, long long ws_floats,
+                                 float* scratch, long long scratch_floats, int B, int H, int W, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ConvDims d;
+  TRY(make_conv_dims(B, H, W, d));
+  DGVIT_CHECK_ARG(img && params && feat && ws && scratch, "dgvit_cnn_forward: null pointer");
+  for (int i = 0; i < 6; ++i) DGVIT_CHECK_ARG(params[i], "cnn parameter %d is null", i);
+  if (ws_floats < dgvit_cnn_workspace_floats(B, H, W) || scratch_floats < dgvit_cnn_forward_scratch_floats(B, H, W))
+    return dgvit_set_error(DGVIT_ERR_WORKSPACE, "dgvit_cnn_forward: workspace or scratch too small");
+  float* act[4] = {nullptr, ws, ws + al4(d.M[1] * 16), ws + al4(d.M[1] * 16) + al4(d.M[2] * 64)};
+  float* cols = scratch;
+  float* wp[3] = {scratch + conv_cols_floats(d), nullptr, nullptr};
+  wp[1] = wp[0] + al4(16 * 28);
+  wp[2] = wp[1] + al4(64 * 400);
+  const float* in = img;
+  for (int l = 0; l < 3; ++l) {
+    TRY(weight_pack(params[2 * l], wp[l], d.C[l + 1], d.C[l], d.KP[l], 0, st));
+    TRY(im2col(in, cols, B, d.H[l], d.W[l], d.C[l], d.H[l + 1], d.W[l + 1], d.KP[l], st));
+    GemmParams p = gp(cols, d.KP[l], wp[l], d.KP[l], act[l + 1], d.C[l + 1], (int)d.M[l + 1], d.C[l + 1], d.KP[l]);
+    p.bias = params[2 * l + 1];
+    TRY(gemm_f32(GEMM_NT, EPI_RELU, p, 1, st));   // relu(conv + bias), rows = next layer's NHWC input
+    in = act[l + 1];
+  }
+  return avgpool(act[3], feat, B, d.H[3] * d.W[3], 256, st);
+}
+
+extern "C" int dgvit_cnn_backward(const float* img, const float* const* params, float* const* grads, const float* dfeat,
+                                  const float* ws, long long ws_floats, float* scratch, long long scratch_floats, int B, int H,
+                                  int W, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ConvDims d;
+  TRY(make_conv_dims(B, H, W, d));
+  DGVIT_CHECK_ARG(img && params && grads && dfeat && ws && scratch, "dgvit_cnn_backward: null pointer");
+  for (int i = 0; i < 6; ++i) DGVIT_CHECK_ARG(params[i] && grads[i], "cnn parameter/gradient %d is null", i);
+  if (ws_floats < dgvit_cnn_workspace_floats(B, H, W) || scratch_floats < dgvit_cnn_backward_scratch_floats(B, H, W))
+    return dgvit_set_error(DGVIT_ERR_WORKSPACE, "dgvit_cnn_backward: workspace or scratch too small");
+  const float* act[4] = {img, ws, ws + al4(d.M[1] * 16), ws + al4(d.M[1] * 16) + al4(d.M[2] * 64)};
+  const long long dyf = al4(std::max(std::max(d.M[1] * 16, d.M[2] * 64), d.M[3] * 256));
+  float* cols = scratch;
+  float* wp = cols + conv_cols_floats(d);          // packed weight of the current layer (largest first)
+  float* dwp = wp + conv_wp_floats(d);             // packed weight gradient
+  float* dya = dwp + conv_wp_floats(d);
+  float* dyb = dya + dyf;
+  float* slabs = dyb + dyf;
+  const long long slab_floats = scratch_floats - (slabs - scratch);
+  // d(avgpool) and the ReLU of conv3
+  TRY(avgpool_bwd_relu(dfeat, act[3], dya, B, d.H[3] * d.W[3], 256, st));
+  float* dy = dya;
+  float* dnext = dyb;
+  for (int l = 2; l >= 0; --l) {
+    const int cout = d.C[l + 1], KP = d.KP[l];
+    const int M = (int)d.M[l + 1];
+    TRY(im2col(act[l], cols, B, d.H[l], d.W[l], d.C[l], d.H[l + 1], d.W[l + 1], KP, st));
+    TRY(wgrad(dy, cout, cols, KP, dwp, grads[2 * l + 1], cout, KP, M, slabs, slab_floats, st));
+    TRY(weight_pack(dwp, grads[2 * l], cout, d.C[l], KP, 1, st));
+    if (l > 0) {
+      TRY(weight_pack(params[2 * l], wp, cout, d.C[l], KP, 0, st));
+      GemmParams p = gp(dy, cout, wp, KP, cols, KP, M, KP, cout);   // dcols = dy W  (cols buffer reused)
+      TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));
+      TRY(col2im_relu(cols, act[l], dnext, B, d.H[l], d.W[l], d.C[l], d.H[l + 1], d.W[l + 1], st));
+      float* t = dy; dy = dnext; dnext = t;
+    }
+  }
+  return DGVIT_OK;
 }

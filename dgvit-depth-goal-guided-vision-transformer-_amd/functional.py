@@ -105,6 +105,56 @@ def got_encoder(img, goal, cfg_tuple, params, dropout_keep=1.0, dropout_seed=0):
     return _GoTEncoder.apply(img, goal, tuple(cfg_tuple), dropout_keep, dropout_seed, need_grad, *params)
 
 
+# ------------------------------------------------------------------------------------------------ CNN feature stack
+class _CnnStack(torch.autograd.Function):
+    """conv1-relu-conv2-relu-conv3-relu-avgpool of QNetwork / GaussianPolicy (got_sac_network.py:151-155) as one node."""
+
+    @staticmethod
+    def forward(ctx, img, need_grad, *params):
+        lib = _lib.load()
+        img = _dev(img, "img")
+        params = [_dev(p, f"conv param[{i}]") for i, p in enumerate(params)]
+        if img.dim() != 3:
+            raise DgvitError(f"img must be (B, H, W), got {tuple(img.shape)}")
+        B, H, W = img.shape
+        nws = lib.dgvit_cnn_workspace_floats(B, H, W)
+        nsc = lib.dgvit_cnn_forward_scratch_floats(B, H, W)
+        if nws < 0 or nsc < 0:
+            _lib.check(-1, "dgvit_cnn_workspace_floats")
+        ws = torch.empty(nws, dtype=torch.float32, device=img.device)
+        scratch = torch.empty(nsc, dtype=torch.float32, device=img.device)
+        feat = torch.empty(B, 256, dtype=torch.float32, device=img.device)
+        with torch.cuda.device(img.device):
+            rc = lib.dgvit_cnn_forward(_ptr(img), _table(params), _ptr(feat), _ptr(ws), nws, _ptr(scratch), nsc, B, H, W, _stream())
+        _lib.check(rc, "dgvit_cnn_forward")
+        if need_grad:
+            ctx.ws = ws
+            ctx.save_for_backward(img, *params)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        lib = _lib.load()
+        img, *params = ctx.saved_tensors
+        dfeat = _dev(dfeat, "dfeat")
+        B, H, W = img.shape
+        grads = [torch.empty_like(p) for p in params]
+        nsc = lib.dgvit_cnn_backward_scratch_floats(B, H, W)
+        scratch = torch.empty(nsc, dtype=torch.float32, device=img.device)
+        with torch.cuda.device(img.device):
+            rc = lib.dgvit_cnn_backward(_ptr(img), _table(params), _table(grads), _ptr(dfeat), _ptr(ctx.ws), ctx.ws.numel(),
+                                        _ptr(scratch), nsc, B, H, W, _stream())
+        _lib.check(rc, "dgvit_cnn_backward")
+        ctx.ws = None
+        return (None, None, *grads)
+
+
+def cnn_features(img, conv_params):
+    """(B, H, W) frames -> (B, 256) pooled features; conv_params = [w1, b1, w2, b2, w3, b3] (reference layouts)."""
+    need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in conv_params)
+    return _CnnStack.apply(img, need_grad, *conv_params)
+
+
 # ------------------------------------------------------------------------------------------------ head Linear
 class _Linear(torch.autograd.Function):
     @staticmethod

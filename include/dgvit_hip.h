@@ -154,6 +154,23 @@ int dgvit_patchify(const float* img, float* patches, int B, int image_h, int ima
 int dgvit_dropout(float* x, long long n, unsigned long long seed, float keep, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * CNN feature stack of the shipped critic QNetwork and of GaussianPolicy
+ * (got_sac_network.py:129-133,151-155 / 263-266,292-296):
+ *   Conv2d(1,16,5,s2) ReLU Conv2d(16,64,5,s2) ReLU Conv2d(64,256,5,s2) ReLU AdaptiveAvgPool2d(1)
+ * img (B, H, W) single channel -> feat (B, 256).  params / grads: conv1.weight (16,1,5,5), conv1.bias,
+ * conv2.weight (64,16,5,5), conv2.bias, conv3.weight (256,64,5,5), conv3.bias in the reference's layouts.
+ * `ws` keeps the three NHWC activations for backward; scratch holds im2col rows, packed weights, split-K slabs.
+ * -------------------------------------------------------------------------------------------- */
+long long dgvit_cnn_workspace_floats(int B, int H, int W);
+long long dgvit_cnn_forward_scratch_floats(int B, int H, int W);
+long long dgvit_cnn_backward_scratch_floats(int B, int H, int W);
+int dgvit_cnn_forward(const float* img, const float* const* params, float* feat, float* ws, long long ws_floats,
+                      float* scratch, long long scratch_floats, int B, int H, int W, void* stream);
+int dgvit_cnn_backward(const float* img, const float* const* params, float* const* grads, const float* dfeat,
+                       const float* ws, long long ws_floats, float* scratch, long long scratch_floats, int B, int H, int W,
+                       void* stream);
+
+/* ----------------------------------------------------------------------------------------------
  * The step after the path: torch.optim.Adam.step over all tensors of a network
  * (DRL.py:401-403,412-414) and the Polyak target update target = target*(1-tau) + source*tau (utils.py:31-33),
  * each as ONE pass over flat fp32 buffers (n multiple of 4, 16-byte aligned; see dgvit_amd.optim).

@@ -362,6 +362,62 @@ def detpolicy_forward(p, istate, pstate, cfg: GoTConfig, drop_mask=None,
 
 
 # --------------------------------------------------------------------------
+# CNN critic / actor
+# --------------------------------------------------------------------------
+def cnn_qnet_param_spec(nb_actions: int = 2, nb_pstate: int = 2):
+    """QNetwork keys (got_sac_network.py:126-144)."""
+    s = [("conv1.weight", (16, 1, 5, 5), "conv"), ("conv1.bias", (16,), "bias"),
+         ("conv2.weight", (64, 16, 5, 5), "conv"), ("conv2.bias", (64,), "bias"),
+         ("conv3.weight", (256, 64, 5, 5), "conv"), ("conv3.bias", (256,), "bias")]
+    s += _lin("fc1", 128, 256 + 32 + nb_actions) + _lin("fc2", 32, 128) + _lin("fc3", nb_actions, 32)
+    s += _lin("fc_embed", 32, nb_pstate)
+    s += _lin("fc11", 128, 256 + 32 + nb_actions) + _lin("fc21", 32, 128) + _lin("fc31", nb_actions, 32)
+    return s
+
+
+def cnn_policy_param_spec(nb_actions: int = 2, nb_pstate: int = 2):
+    """GaussianPolicy keys (got_sac_network.py:259-274)."""
+    s = [("conv1.weight", (16, 1, 5, 5), "conv"), ("conv1.bias", (16,), "bias"),
+         ("conv2.weight", (64, 16, 5, 5), "conv"), ("conv2.bias", (64,), "bias"),
+         ("conv3.weight", (256, 64, 5, 5), "conv"), ("conv3.bias", (256,), "bias")]
+    s += _lin("fc_embed", 32, nb_pstate) + _lin("fc1", 128, 256 + 32) + _lin("fc2", 32, 128)
+    s += _lin("mean_linear", nb_actions, 32) + _lin("log_std_linear", nb_actions, 32)
+    return s
+
+
+def cnn_features(p, istate):
+    """unsqueeze(1) -> relu(conv1) -> relu(conv2) -> relu(conv3) -> global average (got_sac_network.py:150-155)."""
+    x = istate.unsqueeze(1)
+    for i in (1, 2, 3):
+        x = torch.relu(torch.nn.functional.conv2d(x, p[f"conv{i}.weight"], p[f"conv{i}.bias"], stride=2))
+    return x.mean(dim=(2, 3))
+
+
+def cnn_qnet_forward(p, istate, pstate, a):
+    """QNetwork.forward (got_sac_network.py:146-170)."""
+    x1 = cnn_features(p, istate)
+    x2 = torch.relu(linear(pstate, p["fc_embed.weight"], p["fc_embed.bias"]))            # :158
+    x = torch.cat([x1, x2, a], dim=1)                                                      # :160
+    q1 = torch.relu(linear(x, p["fc1.weight"], p["fc1.bias"]))
+    q1 = torch.relu(linear(q1, p["fc2.weight"], p["fc2.bias"]))
+    q1 = linear(q1, p["fc3.weight"], p["fc3.bias"])
+    q2 = torch.relu(linear(x, p["fc11.weight"], p["fc11.bias"]))
+    q2 = torch.relu(linear(q2, p["fc21.weight"], p["fc21.bias"]))
+    q2 = linear(q2, p["fc31.weight"], p["fc31.bias"])
+    return q1, q2
+
+
+def cnn_policy_forward(p, istate, pstate):
+    """GaussianPolicy.forward (got_sac_network.py:288-308): goal embedding WITHOUT activation."""
+    x = torch.cat([cnn_features(p, istate), linear(pstate, p["fc_embed.weight"], p["fc_embed.bias"])], dim=1)
+    x = torch.relu(linear(x, p["fc1.weight"], p["fc1.bias"]))
+    x = torch.relu(linear(x, p["fc2.weight"], p["fc2.bias"]))
+    mean = linear(x, p["mean_linear.weight"], p["mean_linear.bias"])
+    log_std = linear(x, p["log_std_linear.weight"], p["log_std_linear.bias"]).clamp(LOG_SIG_MIN, LOG_SIG_MAX)
+    return mean, log_std
+
+
+# --------------------------------------------------------------------------
 # SAC loss arithmetic the path is differentiated through (DRL.py:390-432)
 # --------------------------------------------------------------------------
 def sac_critic_loss(q1: Tensor, q2: Tensor, y: Tensor) -> Tensor:

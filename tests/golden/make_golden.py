@@ -204,6 +204,30 @@ def case_det(name, cfg, batch, seed):
     save(name, out)
 
 
+def case_cnn(name, kind, batch, seed, image=(128, 160)):
+    """Reference QNetwork / GaussianPolicy (CNN, got_sac_network.py:125-170, 258-327), unmodified classes."""
+    cfg = O.GoTConfig(image=image)
+    if kind == "qnet":
+        m, spec = ref_net.QNetwork(2, 2), O.cnn_qnet_param_spec()
+    else:
+        m, spec = ref_net.GaussianPolicy(2, 2), O.cnn_policy_param_spec()
+    load(m, spec, seed)
+    img, pstate, act, tgt = O.make_inputs(cfg, batch, seed)
+    out = {"meta/image": np.array(image), "meta/batch": np.array(batch), "meta/seed": np.array(seed)}
+    if kind == "qnet":
+        q1, q2 = m([img, pstate, act])
+        loss = torch.nn.functional.mse_loss(q1, tgt.expand_as(q1)) + torch.nn.functional.mse_loss(q2, tgt.expand_as(q2))
+        out["q1"], out["q2"] = q1.detach().numpy(), q2.detach().numpy()
+    else:
+        mean, log_std = m([img, pstate])
+        loss = (mean ** 2).mean() + (log_std ** 2).mean()
+        out["mean"], out["log_std"] = mean.detach().numpy(), log_std.detach().numpy()
+    loss.backward()
+    out["loss"] = np.array(loss.item())
+    grad_summary(m, out, "g")
+    save(name, out)
+
+
 def main():
     C = O.GoTConfig
     # tiny, arbitrary dims (bare GoT; dim_head 32, the smallest the fused attention kernel takes), full gradients
@@ -222,6 +246,10 @@ def main():
     case_policy("policy_c2", c2, 4, 0)
     case_sac("sac_c2", c2, 4, 0)
     case_got("got_c2_mask", c2, 2, 5, with_mask=True)
+    # the shipped CNN critic and the CNN actor, native 128x160 and 84x84
+    case_cnn("cnn_qnet_native", "qnet", 3, 21)
+    case_cnn("cnn_qnet_84", "qnet", 2, 22, image=(84, 84))
+    case_cnn("cnn_policy_native", "policy", 2, 23)
     # C5 shape cut to depth 2: 224x224 @ 16, H12 D768 M3072
     case_got("got_c5_l2", C(image=(224, 224), patch=(16, 16), dim=768, depth=2, heads=12, mlp_dim=3072), 1, 6)
 

@@ -368,3 +368,49 @@ def test_c_abi_error_codes(amd):
         m(torch.rand(2, 80, 84, device="cuda"), goal)
     with pytest.raises(amd.DgvitError, match="fp32"):
         m(img.double(), goal)
+
+
+@pytest.mark.parametrize("name,kind", [("cnn_qnet_native", "qnet"), ("cnn_qnet_84", "qnet"), ("cnn_policy_native", "policy")])
+def test_cnn_networks_golden(amd, name, kind):
+    """HIP QNetwork (the shipped critic) / GaussianPolicy vs the reference's own outputs and gradients."""
+    fx = load_fixture(name)
+    image = tuple(int(v) for v in fx["meta/image"])
+    batch, seed = int(fx["meta/batch"]), int(fx["meta/seed"])
+    spec = O.cnn_qnet_param_spec() if kind == "qnet" else O.cnn_policy_param_spec()
+    m = amd.QNetwork(2, 2) if kind == "qnet" else amd.GaussianPolicy(2, 2)
+    assert [k for k, _ in m.named_parameters()] == [k for k, _, _ in spec]
+    m = _load_state(m, O.make_params(spec, seed)).to("cuda")
+    img, pstate, act, tgt = (t.cuda() for t in O.make_inputs(O.GoTConfig(image=image), batch, seed))
+    if kind == "qnet":
+        q1, q2 = m([img, pstate, act])
+        np.testing.assert_allclose(q1.detach().cpu().numpy(), fx["q1"], rtol=0, atol=OUT_TOL)
+        np.testing.assert_allclose(q2.detach().cpu().numpy(), fx["q2"], rtol=0, atol=OUT_TOL)
+        loss = torch.nn.functional.mse_loss(q1, tgt.expand_as(q1)) + torch.nn.functional.mse_loss(q2, tgt.expand_as(q2))
+    else:
+        mean, log_std = m([img, pstate])
+        np.testing.assert_allclose(mean.detach().cpu().numpy(), fx["mean"], rtol=0, atol=OUT_TOL)
+        np.testing.assert_allclose(log_std.detach().cpu().numpy(), fx["log_std"], rtol=0, atol=OUT_TOL)
+        loss = (mean ** 2).mean() + (log_std ** 2).mean()
+    np.testing.assert_allclose(loss.item(), float(fx["loss"]), rtol=1e-4)
+    loss.backward()
+    check_grad_digest(fx, "g", {k: p.grad for k, p in m.named_parameters()}, rtol=GRAD_RTOL, atol=GRAD_ATOL)
+
+
+def test_cnn_stack_vs_oracle_batch(amd):
+    """Conv stack alone at a ragged batch against the oracle (F.conv2d on CPU), outputs and all conv gradients."""
+    B = 37
+    spec = O.cnn_qnet_param_spec()
+    params = O.make_params(spec, 5)
+    img, _, _, _ = O.make_inputs(O.GoTConfig(image=(84, 84)), B, 5)
+    w = torch.randn(B, 256, generator=torch.Generator().manual_seed(2))
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items() if k.startswith("conv")}
+    ref = O.cnn_features(p, img)
+    (ref * w).sum().backward()
+    names = ["conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "conv3.weight", "conv3.bias"]
+    dev = [params[k].cuda().requires_grad_(True) for k in names]
+    feat = amd.functional.cnn_features(img.cuda(), dev)
+    (feat * w.cuda()).sum().backward()
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=2e-5)
+    for k, t in zip(names, dev):
+        r = p[k].grad.numpy()
+        np.testing.assert_allclose(t.grad.cpu().numpy(), r, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(r).max()), err_msg=k)

@@ -118,3 +118,27 @@ def test_oracle_gradcheck_fp64():
         return O.got_forward(q, img, goal, cfg, prefix="")
 
     assert torch.autograd.gradcheck(f, leaves, eps=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("name,kind", [("cnn_qnet_native", "qnet"), ("cnn_qnet_84", "qnet"), ("cnn_policy_native", "policy")])
+def test_cnn_cases(name, kind):
+    """CNN critic / actor restatement against the reference's unmodified classes."""
+    fx = load_fixture(name)
+    image = tuple(int(v) for v in fx["meta/image"])
+    batch, seed = int(fx["meta/batch"]), int(fx["meta/seed"])
+    spec = O.cnn_qnet_param_spec() if kind == "qnet" else O.cnn_policy_param_spec()
+    p = _leaf_params(spec, seed)
+    img, pstate, act, tgt = O.make_inputs(O.GoTConfig(image=image), batch, seed)
+    if kind == "qnet":
+        q1, q2 = O.cnn_qnet_forward(p, img, pstate, act)
+        np.testing.assert_allclose(q1.detach().numpy(), fx["q1"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(q2.detach().numpy(), fx["q2"], rtol=0, atol=TOL)
+        loss = O.sac_critic_loss(q1, q2, tgt)
+    else:
+        mean, log_std = O.cnn_policy_forward(p, img, pstate)
+        np.testing.assert_allclose(mean.detach().numpy(), fx["mean"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(log_std.detach().numpy(), fx["log_std"], rtol=0, atol=TOL)
+        loss = (mean ** 2).mean() + (log_std ** 2).mean()
+    np.testing.assert_allclose(loss.item(), float(fx["loss"]), rtol=1e-5)
+    loss.backward()
+    check_grad_digest(fx, "g", {k: v.grad for k, v in p.items()}, rtol=5e-4, atol=2e-6)
