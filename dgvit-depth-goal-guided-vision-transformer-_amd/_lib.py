@@ -60,6 +60,7 @@ SIGNATURES = {
     "dgvit_cnn_backward_scratch_floats": (_LL, [_I, _I, _I]),
     "dgvit_cnn_forward": (_I, [_P, _TABLE, _P, _P, _LL, _P, _LL, _I, _I, _I, _P]),
     "dgvit_cnn_backward": (_I, [_P, _TABLE, _TABLE, _P, _P, _LL, _P, _LL, _I, _I, _I, _P]),
+    "dgvit_gather_rows": (_I, [_P, _P, _P, _LL, _LL, _LL, _P]),
     "dgvit_adam_step": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _F, _LL, _P]),
     "dgvit_soft_update": (_I, [_P, _P, _LL, _F, _P]),
     "dgvit_profile_start": (_I, [_I]),

@@ -31,6 +31,7 @@ int col2im_relu(const float*, const float*, float*, int, int, int, int, int, int
 int weight_pack(const float*, float*, int, int, int, int, hipStream_t);
 int avgpool(const float*, float*, int, int, int, hipStream_t);
 int avgpool_bwd_relu(const float*, const float*, float*, int, int, int, hipStream_t);
+int gather_rows(const float*, const long long*, float*, long long, long long, long long, hipStream_t);
 extern int g_gemm_tile_hint;
 static int g_prune_last = 1;  // last block: only token 0 feeds the output (GoalFormer.py:167)
 static int g_overlap_wgrad = 0;  // opt-in: run weight-gradient GEMMs on a helper stream beside the data-gradient chain
@@ -673,4 +674,10 @@ extern "C" int dgvit_cnn_backward(const float* img, const float* const* params, 
     }
   }
   return DGVIT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- replay staging
+extern "C" int dgvit_gather_rows(const float* src, const long long* idx, float* out, long long nsel, long long row_floats,
+                                 long long nrows, void* stream) {
+  return gather_rows(src, idx, out, nsel, row_floats, nrows, (hipStream_t)stream);
 }

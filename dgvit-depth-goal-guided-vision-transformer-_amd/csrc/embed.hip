@@ -64,7 +64,30 @@ __global__ void __launch_bounds__(256) relu_bwd_kernel(const float* __restrict__
   if (i < n) out[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 
+// out[i][:] = src[idx[i]][:] for rows of `row4` float4 (device-resident replay sampling)
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ idx,
+                                                          float* __restrict__ out, long long total4, int row4, long long nrows) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const long long r = i / row4;
+  const int c = (int)(i % row4);
+  long long s = idx[r];
+  s = s < 0 ? 0 : (s >= nrows ? nrows - 1 : s);   // clamp instead of faulting on a bad index
+  reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(src)[s * row4 + c];
+}
+
 }  // namespace
+
+int gather_rows(const float* src, const long long* idx, float* out, long long nsel, long long row_floats, long long nrows,
+                hipStream_t stream) {
+  DGVIT_CHECK_ARG(src && idx && out && nsel > 0 && nrows > 0, "gather_rows: bad arguments");
+  DGVIT_CHECK_ARG(row_floats > 0 && row_floats % 4 == 0 && row_floats / 4 < (1ll << 31), "gather_rows: row length must be a multiple of 4 floats");
+  const long long total4 = nsel * (row_floats / 4);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, src, idx, out, total4,
+                     (int)(row_floats / 4), nrows);
+  DGVIT_CHECK_LAUNCH("gather_rows");
+  return DGVIT_OK;
+}
 
 int patchify(const float* img, float* out, int B, int Hi, int Wi, int ph, int pw, hipStream_t stream) {
   DGVIT_CHECK_ARG(img && out && B > 0, "patchify: bad arguments");

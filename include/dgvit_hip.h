@@ -171,6 +171,15 @@ int dgvit_cnn_backward(const float* img, const float* const* params, float* cons
                        void* stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * the step BEFORE the path.  The reference samples numpy batches from cpprb and copies
+ * (B,128,160) fp32 obs / next_obs to the device every step (DRL.py:375-386).  With the transitions resident in HBM
+ * (dgvit_amd.replay.DeviceReplayBuffer) a sample is an index draw plus this gather:
+ *   out[i][0..row_floats) = src[idx[i]][0..row_floats)      idx: int64 device array, row_floats % 4 == 0
+ * -------------------------------------------------------------------------------------------- */
+int dgvit_gather_rows(const float* src, const long long* idx, float* out, long long nsel, long long row_floats,
+                      long long nrows, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
  * The step after the path: torch.optim.Adam.step over all tensors of a network
  * (DRL.py:401-403,412-414) and the Polyak target update target = target*(1-tau) + source*tau (utils.py:31-33),
  * each as ONE pass over flat fp32 buffers (n multiple of 4, 16-byte aligned; see dgvit_amd.optim).

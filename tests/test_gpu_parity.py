@@ -414,3 +414,34 @@ def test_cnn_stack_vs_oracle_batch(amd):
     for k, t in zip(names, dev):
         r = p[k].grad.numpy()
         np.testing.assert_allclose(t.grad.cpu().numpy(), r, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(r).max()), err_msg=k)
+
+
+def test_device_replay_buffer(amd):
+    """device-resident replay; sampled rows must be the stored transitions at the drawn indices,
+    the ring must wrap, and the index draw must be uniform over the stored range."""
+    from dgvit_amd.replay import DeviceReplayBuffer
+    rb = DeviceReplayBuffer(32, obs_shape=(12, 10), seed=0)
+    rs = np.random.RandomState(0)
+    data = []
+    for i in range(45):                                     # wraps the 32-slot ring
+        tr = dict(obs=rs.rand(12, 10).astype(np.float32), pobs=rs.rand(2), act=rs.rand(2) * 2 - 1, rew=float(i),
+                  next_obs=rs.rand(12, 10).astype(np.float32), next_pobs=rs.rand(2), done=float(i % 2))
+        rb.add(**tr)
+        data.append(tr)
+    assert rb.get_stored_size() == 32
+    batch = rb.sample(64)
+    idx = batch["indexes"].cpu().numpy()
+    assert batch["obs"].shape == (64, 12, 10) and batch["pobs"].shape == (64, 2) and batch["rew"].shape == (64, 1)
+    assert batch["obs"].is_cuda
+    for j, slot in enumerate(idx):
+        src = data[slot if slot >= 45 - 32 else slot + 32]  # slot s holds transition s or s+32 after the wrap
+        np.testing.assert_array_equal(batch["obs"][j].cpu().numpy(), src["obs"])
+        np.testing.assert_array_equal(batch["next_obs"][j].cpu().numpy(), src["next_obs"])
+        np.testing.assert_allclose(batch["act"][j].cpu().numpy(), src["act"].astype(np.float32))
+        assert batch["rew"][j].item() == src["rew"] and batch["done"][j].item() == src["done"]
+    counts = np.bincount(rb.sample_indices(64000).cpu().numpy(), minlength=32)
+    assert counts.min() > 1700 and counts.max() < 2300     # uniform: 2000 +- 5 sigma(=44)
+    # sampled frames feed the encoder directly
+    m = amd.GoTPolicy(2, 2, 1, 2, 64, image_size=(12, 10), patch_size=(6, 5)).to("cuda").eval()
+    mean, _ = m([batch["obs"], batch["pobs"]])
+    assert torch.isfinite(mean).all()

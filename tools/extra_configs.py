@@ -88,3 +88,24 @@ def fb5():
 
 
 report("C5-shape B=64 fwd+bwd ViT-Base 224x224@16 in fp32", cfg, 64, timed(fb5, 2, 5), 3)
+
+# the shipped critic (CNN QNetwork) and the shipped training step (GoT actor L4/H4/D64 + CNN critic)
+q = dgvit_amd.QNetwork(2, 2).to(dev)
+Bq = 512
+img, ps, act, tgt = (t.to(dev) for t in O.make_inputs(C(), Bq, 0))
+
+
+def qfb():
+    q.zero_grad(set_to_none=True)
+    q1, q2 = q([img, ps, act])
+    (torch.nn.functional.mse_loss(q1, tgt.expand_as(q1)) + torch.nn.functional.mse_loss(q2, tgt.expand_as(q2))).backward()
+
+
+dt = timed(qfb)
+conv_flops = 2.0 * (62 * 78 * 16 * 25 + 29 * 37 * 64 * 400 + 13 * 17 * 256 * 1600)
+print(json.dumps({"config": "f1 CNN QNetwork fwd+bwd B=512 128x160", "ms": round(dt * 1e3, 3), "frames_per_s": round(Bq / dt, 1),
+                  "tflops_dense": round(Bq / dt * 3 * conv_flops / 1e12, 2)}), flush=True)
+with torch.no_grad():
+    dt = timed(lambda: q([img, ps, act]))
+print(json.dumps({"config": "f1 CNN QNetwork fwd-only B=512 128x160", "ms": round(dt * 1e3, 3), "frames_per_s": round(Bq / dt, 1),
+                  "tflops_dense": round(Bq / dt * conv_flops / 1e12, 2)}), flush=True)
