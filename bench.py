@@ -75,7 +75,7 @@ def cpu_baseline(batch):
                       f"{torch.get_num_threads()} torch threads"}
 
 
-def sac_step(dgvit_amd, O, cfg, B, dev, steps=5):
+def sac_step(dgvit_amd, synthetic, B, dev, steps=5):
     """Secondary number (SURVEY 8(d) C3 "secondary"): one SAC-style update with transformer actor AND transformer
     critic, losses as DRL.py:390-432 (alpha fixed 0.2, gamma 0.99): 2 no-grad target passes, critic fwd+bwd,
     actor fwd + critic fwd + bwd through both, two Adam steps, Polyak update.  5 encoder forwards and 3 encoder
@@ -89,8 +89,8 @@ def sac_step(dgvit_amd, O, cfg, B, dev, steps=5):
     tgt = copy.deepcopy(crt)
     flatten_parameters(crt), flatten_parameters(tgt)
     opt_p, opt_c = FlatAdam([pol], lr=1e-4), FlatAdam([crt], lr=1e-4)
-    img, pstate, act, _ = (t.to(dev) for t in O.make_inputs(cfg, B, 11))
-    nimg, npst, _, _ = (t.to(dev) for t in O.make_inputs(cfg, B, 12))
+    img, pstate, act, _ = (t.to(dev) for t in synthetic.make_inputs(IMAGE, B, 11))
+    nimg, npst, _, _ = (t.to(dev) for t in synthetic.make_inputs(IMAGE, B, 12))
     rew = torch.randn(B, 1, device=dev)
     alpha, gamma, tau = 0.2, 0.99, 0.005
 
@@ -150,12 +150,11 @@ def main():
     import dgvit_amd
     from dgvit_amd.parallel import GradSync
     from dgvit_amd import _lib
-    from oracle import dgvit_oracle as O   # inputs + FLOP model + cpu_baseline only; never on the measured path
+    import synthetic                         # input generator + FLOP model (oracle/ is only imported by cpu_baseline())
     lib = dgvit_amd.load_library()
     lib.dgvit_set_wgrad_overlap(1 if args.wgrad_overlap else 0)
     lib.dgvit_set_prune_last_layer(0 if args.dense_last_block else 1)
 
-    cfg = O.GoTConfig(image=IMAGE, patch=PATCH, dim=DIM, depth=DEPTH, heads=HEADS)
     B = args.batch
     torch.manual_seed(3407)                      # identical initial weights on every rank (config.yaml:7 SEED)
     model = dgvit_amd.GoTPolicy(2, 2, DEPTH, HEADS, DIM, image_size=IMAGE, patch_size=PATCH).to(dev).train()
@@ -163,7 +162,7 @@ def main():
     sync.broadcast_parameters(0)
     from dgvit_amd.optim import FlatAdam
     opt = FlatAdam([model], lr=1e-4)            # torch.optim.Adam semantics, one HIP kernel per flat block
-    img, pstate, _, _ = (t.to(dev) for t in O.make_inputs(cfg, B, 3407 + rank))   # rank-local frames, resident in HBM
+    img, pstate, _, _ = (t.to(dev) for t in synthetic.make_inputs(IMAGE, B, 3407 + rank))   # rank-local frames, resident in HBM
     g = torch.Generator(device="cpu").manual_seed(rank)
     tgt_mean, tgt_ls = torch.randn(B, 2, generator=g).to(dev), torch.randn(B, 2, generator=g).to(dev)
     torch.manual_seed(1000 + rank)               # decorrelate dropout masks across ranks
@@ -207,7 +206,7 @@ def main():
     if rank == 0:
         frames = B * world * args.steps
         fps = frames / dt
-        fwd = cfg.fwd_flops_per_frame()
+        fwd = synthetic.fwd_flops_per_frame(IMAGE, PATCH, DIM, DEPTH, HEADS)
         gemm_tflops = (work[0] / 1e12) / (ms[0] / 1e3) if ms[0] > 0 else 0.0
         traffic = None
         try:   # HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (tools/pmc_traffic.py)
@@ -238,7 +237,7 @@ def main():
                            "attn_bwd_ms_per_step": round(ms[2] / args.steps, 3), "final_loss": round(final_loss, 5)},
         }
         if world == 1 and not args.no_sac_step:
-            out["sac_step"] = sac_step(dgvit_amd, O, cfg, B, dev)
+            out["sac_step"] = sac_step(dgvit_amd, synthetic, B, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(out), flush=True)

@@ -5,7 +5,23 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import dgvit_amd
-from oracle import dgvit_oracle as O
+import synthetic
+
+
+class C:   # shape record with the FLOP model (tools must not import oracle/)
+    def __init__(self, image=(128, 160), patch=(16, 20), dim=64, depth=4, heads=4, mlp_dim=2048):
+        self.image, self.patch, self.dim, self.depth, self.heads, self.mlp_dim = image, patch, dim, depth, heads, mlp_dim
+
+    def fwd_flops_per_frame(self):
+        return synthetic.fwd_flops_per_frame(self.image, self.patch, self.dim, self.depth, self.heads, 64, self.mlp_dim)
+
+
+class O:   # minimal stand-in namespace used below
+    GoTConfig = C
+
+    @staticmethod
+    def make_inputs(cfg, batch, seed):
+        return synthetic.make_inputs(cfg.image, batch, seed)
 
 dev = "cuda"
 
@@ -32,7 +48,6 @@ def report(name, cfg, B, dt, passes):
                       "tflops_dense": round(B / dt * fl / 1e12, 2), "frac_of_f32_mfma_peak": round(B / dt * fl / 1e12 / 157.3, 4)}), flush=True)
 
 
-C = O.GoTConfig
 # C1: single frame, shipped model, 128x160, sample() (what SAC.choose_action runs, DRL.py:170-185)
 cfg = C(dim=64, depth=4, heads=4)
 m = policy(cfg).eval()

@@ -4,7 +4,23 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import dgvit_amd
-from oracle import dgvit_oracle as O
+import synthetic
+
+
+class C:   # shape record with the FLOP model (tools must not import oracle/)
+    def __init__(self, image=(128, 160), patch=(16, 20), dim=64, depth=4, heads=4, mlp_dim=2048):
+        self.image, self.patch, self.dim, self.depth, self.heads, self.mlp_dim = image, patch, dim, depth, heads, mlp_dim
+
+    def fwd_flops_per_frame(self):
+        return synthetic.fwd_flops_per_frame(self.image, self.patch, self.dim, self.depth, self.heads, 64, self.mlp_dim)
+
+
+class O:   # minimal stand-in namespace used below
+    GoTConfig = C
+
+    @staticmethod
+    def make_inputs(cfg, batch, seed):
+        return synthetic.make_inputs(cfg.image, batch, seed)
 dev = "cuda"
 cfg = O.GoTConfig(dim=64, depth=4, heads=4)
 torch.manual_seed(0)
