@@ -22,7 +22,7 @@ class dgvit_config(Structure):
 
 NUM_GLOBAL_PARAMS = 4
 PARAMS_PER_LAYER = 11
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _P, _I, _LL, _F, _ULL = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 _CFG = POINTER(dgvit_config)
@@ -35,8 +35,8 @@ SIGNATURES = {
     "dgvit_device_count": (_I, []),
     "dgvit_got_workspace_floats": (_LL, [_CFG, _I, _I]),
     "dgvit_got_backward_scratch_floats": (_LL, [_CFG, _I]),
-    "dgvit_got_forward": (_I, [_CFG, _TABLE, _P, _P, _P, _P, _LL, _I, _I, _F, _ULL, _P]),
-    "dgvit_got_backward": (_I, [_CFG, _TABLE, _TABLE, _P, _P, _P, _LL, _P, _LL, _I, _F, _ULL, _P]),
+    "dgvit_got_forward": (_I, [_CFG, _TABLE, _P, _P, _P, _P, _LL, _I, _I, _F, _ULL, _P, _P]),
+    "dgvit_got_backward": (_I, [_CFG, _TABLE, _TABLE, _P, _P, _P, _LL, _P, _LL, _I, _F, _ULL, _P, _P]),
     "dgvit_linear_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dgvit_linear_backward_scratch_floats": (_LL, [_I, _I, _I]),
     "dgvit_linear_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
@@ -61,7 +61,7 @@ SIGNATURES = {
     "dgvit_cnn_forward": (_I, [_P, _TABLE, _P, _P, _LL, _P, _LL, _I, _I, _I, _P]),
     "dgvit_cnn_backward": (_I, [_P, _TABLE, _TABLE, _P, _P, _LL, _P, _LL, _I, _I, _I, _P]),
     "dgvit_gather_rows": (_I, [_P, _P, _P, _LL, _LL, _LL, _P]),
-    "dgvit_adam_step": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _F, _LL, _P]),
+    "dgvit_adam_step": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _F, _LL, _P, _P]),
     "dgvit_soft_update": (_I, [_P, _P, _LL, _F, _P]),
     "dgvit_profile_start": (_I, [_I]),
     "dgvit_profile_stop": (_I, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_longlong)]),

@@ -22,9 +22,10 @@ int attention_fwd(const float*, float*, int, int, int, int, int, hipStream_t);
 int attention_bwd(const float*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 int patchify(const float*, float*, int, int, int, int, int, hipStream_t);
 int goal_row(const float*, const float*, float*, int, int, int, hipStream_t);
-int dropout_inplace(float*, long long, unsigned long long, float, hipStream_t);
+int dropout_inplace(float*, long long, unsigned long long, const unsigned long long*, float, hipStream_t);
 int relu_bwd(const float*, const float*, float*, long long, hipStream_t);
-int adam_step(float*, const float*, float*, float*, long long, float, float, float, float, float, long long, hipStream_t);
+int adam_step(float*, const float*, float*, float*, long long, float, float, float, float, float, long long, const long long*,
+              hipStream_t);
 int soft_update(float*, const float*, long long, float, hipStream_t);
 int im2col(const float*, float*, int, int, int, int, int, int, int, hipStream_t);
 int col2im_relu(const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
@@ -273,7 +274,7 @@ enum { L_LN1W = 0, L_LN1B, L_QKV, L_OUTW, L_OUTB, L_LN2W, L_LN2B, L_FC1W, L_FC1B
 
 extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* params, const float* img, const float* goal,
                                  float* feat, float* ws, long long ws_floats, int batch, int save, float keep,
-                                 unsigned long long seed, void* stream) {
+                                 unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   Dims d;
   TRY(make_dims(cfg, batch, d));
@@ -296,7 +297,7 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
   }
   TRY(goal_row(goal, params[P_POS], x, d.B, d.N, d.D, st));
-  if (keep < 1.f) TRY(dropout_inplace(x, d.T * d.D, seed, keep, st));
+  if (keep < 1.f) TRY(dropout_inplace(x, d.T * d.D, seed, seed_dev, keep, st));
 
   for (int i = 0; i < d.L; ++i) {
     const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
@@ -344,7 +345,8 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
 
 extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* params, float* const* grads, const float* dfeat,
                                   float* dgoal, const float* ws, long long ws_floats, float* scratch, long long scratch_floats,
-                                  int batch, float keep, unsigned long long seed, void* stream) {
+                                  int batch, float keep, unsigned long long seed, const unsigned long long* seed_dev,
+                                  void* stream) {
   hipStream_t st = (hipStream_t)stream;
   Dims d;
   TRY(make_dims(cfg, batch, d));
@@ -436,7 +438,7 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
     TRY(layernorm_bwd(dln, xin, lb + w.mean1, lb + w.rstd1, lp[L_LN1W], dx2, dx, lg[L_LN1W], lg[L_LN1B], part, T, d.D, 1, st));
   }
   // ---- token assembly: x0 = dropout(cat(goal, patches W^T + b) + pos)
-  if (keep < 1.f) TRY(dropout_inplace(dx, d.T * d.D, seed, keep, st));
+  if (keep < 1.f) TRY(dropout_inplace(dx, d.T * d.D, seed, seed_dev, keep, st));
   if (dgoal)
     HIP_TRY(hipMemcpy2DAsync(dgoal, sizeof(float) * d.D, dx, sizeof(float) * d.N * d.D, sizeof(float) * d.D, d.B,
                              hipMemcpyDeviceToDevice, st));
@@ -552,13 +554,13 @@ extern "C" int dgvit_patchify(const float* img, float* patches, int B, int ih, i
   return patchify(img, patches, B, ih, iw, ph, pw, (hipStream_t)stream);
 }
 extern "C" int dgvit_dropout(float* x, long long n, unsigned long long seed, float keep, void* stream) {
-  return dropout_inplace(x, n, seed, keep, (hipStream_t)stream);
+  return dropout_inplace(x, n, seed, nullptr, keep, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------- optimiser step
 extern "C" int dgvit_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                               float eps, float weight_decay, long long step, void* stream) {
-  return adam_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+                               float eps, float weight_decay, long long step, const long long* step_dev, void* stream) {
+  return adam_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, step_dev, (hipStream_t)stream);
 }
 extern "C" int dgvit_soft_update(float* target, const float* source, long long n, float tau, void* stream) {
   return soft_update(target, source, n, tau, (hipStream_t)stream);

@@ -44,9 +44,11 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
   return ctr;
 }
 
-__global__ void __launch_bounds__(256) dropout_kernel(float* __restrict__ x, long long n4, unsigned long long seed, float keep) {
+__global__ void __launch_bounds__(256) dropout_kernel(float* __restrict__ x, long long n4, unsigned long long seed,
+                                                      const unsigned long long* __restrict__ seed_dev, float keep) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
+  if (seed_dev) seed = *seed_dev;   // graph-capturable form: the seed lives in device memory
   const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)(i >> 32), 0u, 0u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
   const float inv = 1.0f / keep;
   const float sc = 2.3283064365386963e-10f;  // 2^-32
@@ -106,10 +108,11 @@ int goal_row(const float* goal, const float* pos, float* x0, int B, int N, int D
   return DGVIT_OK;
 }
 
-int dropout_inplace(float* x, long long n, unsigned long long seed, float keep, hipStream_t stream) {
+int dropout_inplace(float* x, long long n, unsigned long long seed, const unsigned long long* seed_dev, float keep,
+                    hipStream_t stream) {
   DGVIT_CHECK_ARG(x && n > 0 && n % 4 == 0 && keep > 0.f && keep <= 1.f, "dropout: bad arguments (n must be a multiple of 4)");
   const long long n4 = n / 4;
-  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, n4, seed, keep);
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, n4, seed, seed_dev, keep);
   DGVIT_CHECK_LAUNCH("dropout");
   return DGVIT_OK;
 }

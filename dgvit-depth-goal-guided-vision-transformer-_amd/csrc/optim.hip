@@ -10,7 +10,13 @@ namespace {
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n4, float lr_c, float beta1, float beta2,
-                                                   float inv_sqrt_bc2, float eps, float wd) {
+                                                   float inv_sqrt_bc2, float eps, float wd, float lr,
+                                                   const long long* __restrict__ step_dev) {
+  if (step_dev) {   // graph-capturable form: bias corrections from the device-side step counter
+    const float t = (float)*step_dev;
+    lr_c = lr / (1.f - powf(beta1, t));
+    inv_sqrt_bc2 = rsqrtf(1.f - powf(beta2, t));
+  }
   const long long stride = (long long)gridDim.x * 256;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     float4 pv = reinterpret_cast<float4*>(p)[i];
@@ -57,15 +63,15 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 // n must be a multiple of 4 and the buffers 16-byte aligned (the flat buffers of dgvit_amd.optim are)
 int adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
-              float weight_decay, long long step, hipStream_t stream) {
+              float weight_decay, long long step, const long long* step_dev, hipStream_t stream) {
   DGVIT_CHECK_ARG(p && g && m && v && n > 0 && n % 4 == 0, "adam_step: n must be a positive multiple of 4");
   DGVIT_CHECK_ARG(al16(p) && al16(g) && al16(m) && al16(v), "adam_step: buffers must be 16-byte aligned");
-  DGVIT_CHECK_ARG(step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adam_step: bad hyper-parameters");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  DGVIT_CHECK_ARG((step >= 1 || step_dev) && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "adam_step: bad hyper-parameters");
+  const double bc1 = 1.0 - pow((double)beta1, (double)(step >= 1 ? step : 1));
+  const double bc2 = 1.0 - pow((double)beta2, (double)(step >= 1 ? step : 1));
   const int slot = profile_begin(PROF_OTHER, 0.0, stream);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, p, g, m, v, n / 4, (float)(lr / bc1), beta1, beta2,
-                     (float)(1.0 / sqrt(bc2)), eps, weight_decay);
+                     (float)(1.0 / sqrt(bc2)), eps, weight_decay, lr, step_dev);
   profile_end(slot, stream);
   DGVIT_CHECK_LAUNCH("adam_step");
   return DGVIT_OK;

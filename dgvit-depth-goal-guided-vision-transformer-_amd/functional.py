@@ -62,12 +62,16 @@ class _GoTEncoder(torch.autograd.Function):
             _lib.check(-1, "dgvit_got_workspace_floats")
         ws = torch.empty(nws, dtype=torch.float32, device=img.device)
         feat = torch.empty(B, cfg.dim, dtype=torch.float32, device=img.device)
+        # `seed` is a host int, or a 1-element int64 DEVICE tensor (graph capture: the kernel reads it at run time)
+        seed_dev = seed if isinstance(seed, torch.Tensor) else None
+        seed_val = 0 if seed_dev is not None else int(seed)
         with torch.cuda.device(img.device):
             rc = lib.dgvit_got_forward(ctypes.byref(cfg), _table(params), _ptr(img), _ptr(goal), _ptr(feat), _ptr(ws), nws, B,
-                                       int(need_grad), float(keep), int(seed), _stream())
+                                       int(need_grad), float(keep), seed_val, _ptr(seed_dev), _stream())
         _lib.check(rc, "dgvit_got_forward")
         if need_grad:
-            ctx.cfg_tuple, ctx.keep, ctx.seed, ctx.batch = cfg_tuple, float(keep), int(seed), B
+            ctx.cfg_tuple, ctx.keep, ctx.seed, ctx.batch = cfg_tuple, float(keep), seed_val, B
+            ctx.seed_dev = seed_dev
             ctx.ws = ws
             ctx.save_for_backward(*params)
         return feat
@@ -93,7 +97,7 @@ class _GoTEncoder(torch.autograd.Function):
         scratch = torch.empty(nsc, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             rc = lib.dgvit_got_backward(ctypes.byref(cfg), _table(params), _table(grads), _ptr(dfeat), _ptr(dgoal), _ptr(ctx.ws),
-                                        ctx.ws.numel(), _ptr(scratch), nsc, B, ctx.keep, ctx.seed, _stream())
+                                        ctx.ws.numel(), _ptr(scratch), nsc, B, ctx.keep, ctx.seed, _ptr(ctx.seed_dev), _stream())
         _lib.check(rc, "dgvit_got_backward")
         ctx.ws = None
         return (None, dgoal, None, None, None, None, *grads)

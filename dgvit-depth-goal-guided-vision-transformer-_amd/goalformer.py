@@ -121,5 +121,10 @@ class GoT(nn.Module):
         keep, seed = 1.0, 0
         if self.training and self.dropout.p > 0:
             keep = 1.0 - self.dropout.p
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())   # CPU generator: follows torch.manual_seed, no device sync
+            if img.is_cuda and torch.cuda.is_current_stream_capturing():
+                # inside a HIP-graph capture a host seed would be frozen into every replay: draw it on the device
+                # (graph-safe generator) and let the dropout kernel read it from memory
+                seed = torch.empty(1, dtype=torch.int64, device=img.device).random_()
+            else:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())   # CPU generator: follows torch.manual_seed, no device sync
         return F_.got_encoder(img, goal, self._cfg, self.param_table(), keep, seed)

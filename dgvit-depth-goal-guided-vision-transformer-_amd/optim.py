@@ -73,10 +73,13 @@ class FlatAdam:
     ``modules``: the networks to optimise.  Every ``GoT`` encoder inside becomes one block in parameter-table
     order (matching the fused backward's gradient buffer); all remaining parameters that receive gradients form
     one more block, built on the first ``step()``.  Parameters that never get a gradient are left alone, like
-    torch's optimisers do.  Build it after ``module.to(device)``.
+    torch's optimisers do.  Build it after ``module.to(device)``.  ``capturable=True`` keeps the step counter in device
+    memory (like torch's ``capturable`` optimisers) so that ``step()`` can be recorded into a HIP graph.
     """
 
-    def __init__(self, modules: Iterable[torch.nn.Module], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, modules: Iterable[torch.nn.Module], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 capturable: bool = False):
+        self.capturable, self._step_dev = bool(capturable), None
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
         self.modules = list(modules) if not isinstance(modules, torch.nn.Module) else [modules]
         self.step_count = 0
@@ -120,6 +123,12 @@ class FlatAdam:
         if not self._rest_built:
             self._build_rest()
         self.step_count += 1
+        step_ptr = ctypes.c_void_p(0)
+        if self.capturable:
+            if self._step_dev is None:
+                self._step_dev = torch.full((1,), self.step_count - 1, dtype=torch.int64, device=self.blocks[0].flat.device)
+            self._step_dev += 1                      # a device op: replayed with the graph
+            step_ptr = ctypes.c_void_p(self._step_dev.data_ptr())
         for b in self.blocks:
             if any(p.grad is None for p in b.params):
                 raise _lib.DgvitError("FlatAdam: a parameter of a flat block has no gradient this step")
@@ -129,7 +138,7 @@ class FlatAdam:
             with torch.cuda.device(b.flat.device):
                 rc = lib.dgvit_adam_step(ctypes.c_void_p(b.flat.data_ptr()), ctypes.c_void_p(g.data_ptr()),
                                          ctypes.c_void_p(b.exp_avg.data_ptr()), ctypes.c_void_p(b.exp_avg_sq.data_ptr()), b.numel,
-                                         self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, _stream())
+                                         self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, step_ptr, _stream())
             _lib.check(rc, "dgvit_adam_step")
 
     def state_dict(self):

@@ -21,7 +21,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define DGVIT_ABI_VERSION 1
+#define DGVIT_ABI_VERSION 2
 
 /* error codes */
 #define DGVIT_OK 0
@@ -78,10 +78,13 @@ long long dgvit_got_backward_scratch_floats(const dgvit_config* cfg, int batch);
  * (GoalFormer.py:31-122).
  *   img  (B, image_h, image_w)   goal (B, D)   ->   feat (B, D)
  * dropout_keep < 1 applies train-mode nn.Dropout(emb_dropout) (GoalFormer.py:163) with a Philox mask
- * derived from dropout_seed; pass 1.0f for eval mode. */
+ * derived from dropout_seed; pass 1.0f for eval mode.  dropout_seed_dev (may be NULL): a DEVICE pointer to the
+ * seed, read by the kernel at run time and overriding dropout_seed -- the form to use inside a captured HIP
+ * graph, where a by-value seed would be frozen into every replay. */
 int dgvit_got_forward(const dgvit_config* cfg, const float* const* params, const float* img, const float* goal,
                       float* feat, float* workspace, long long workspace_floats, int batch, int save_for_backward,
-                      float dropout_keep, unsigned long long dropout_seed, void* stream);
+                      float dropout_keep, unsigned long long dropout_seed, const unsigned long long* dropout_seed_dev,
+                      void* stream);
 
 /* Gradient of dgvit_got_forward (what autograd derives for GoalFormer.py:156-171).
  *   dfeat (B, D) -> grads[] (same table order as params, each written, not accumulated), dgoal (B, D).
@@ -89,7 +92,7 @@ int dgvit_got_forward(const dgvit_config* cfg, const float* const* params, const
 int dgvit_got_backward(const dgvit_config* cfg, const float* const* params, float* const* grads, const float* dfeat,
                        float* dgoal, const float* workspace, long long workspace_floats, float* scratch,
                        long long scratch_floats, int batch, float dropout_keep, unsigned long long dropout_seed,
-                       void* stream);
+                       const unsigned long long* dropout_seed_dev, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Head Linears (got_sac_network.py:111,115-121,226,230-234,429,433-435):  y = act(x W^T + b)
@@ -184,10 +187,11 @@ int dgvit_gather_rows(const float* src, const long long* idx, float* out, long l
  * (DRL.py:401-403,412-414) and the Polyak target update target = target*(1-tau) + source*tau (utils.py:31-33),
  * each as ONE pass over flat fp32 buffers (n multiple of 4, 16-byte aligned; see dgvit_amd.optim).
  * Adam follows torch.optim.Adam: m,v updates, bias corrections with `step` (1-based), eps added to sqrt(v_hat),
- * weight_decay as L2 term added to the gradient.
+ * weight_decay as L2 term added to the gradient.  step_dev (may be NULL): DEVICE pointer to the 1-based step
+ * counter, overriding `step` (graph-capturable form: bias corrections are then computed in the kernel).
  * -------------------------------------------------------------------------------------------- */
 int dgvit_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                    float eps, float weight_decay, long long step, void* stream);
+                    float eps, float weight_decay, long long step, const long long* step_dev, void* stream);
 int dgvit_soft_update(float* target, const float* source, long long n, float tau, void* stream);
 
 /* ----------------------------------------------------------------------------------------------

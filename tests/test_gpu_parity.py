@@ -357,11 +357,11 @@ def test_c_abi_error_codes(amd):
     tbl = (ctypes.c_void_p * 15)(*[p.data_ptr() for p in m.param_table()])
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
-    assert lib.dgvit_got_forward(ctypes.byref(cfg), tbl, P(img), P(goal), P(feat), P(ws), n - 1, 2, 1, 1.0, 0, st) == -4
+    assert lib.dgvit_got_forward(ctypes.byref(cfg), tbl, P(img), P(goal), P(feat), P(ws), n - 1, 2, 1, 1.0, 0, None, st) == -4
     assert b"workspace" in lib.dgvit_last_error()
-    assert lib.dgvit_got_forward(ctypes.byref(cfg), tbl, None, P(goal), P(feat), P(ws), n, 2, 1, 1.0, 0, st) == -1
-    assert lib.dgvit_got_forward(ctypes.byref(cfg), tbl, P(img), P(goal), P(feat), P(ws), n, 2, 1, 1.5, 0, st) == -1
-    assert lib.dgvit_got_forward(ctypes.byref(cfg), tbl, P(img), P(goal), P(feat), P(ws), n, 2, 1, 1.0, 0, st) == 0
+    assert lib.dgvit_got_forward(ctypes.byref(cfg), tbl, None, P(goal), P(feat), P(ws), n, 2, 1, 1.0, 0, None, st) == -1
+    assert lib.dgvit_got_forward(ctypes.byref(cfg), tbl, P(img), P(goal), P(feat), P(ws), n, 2, 1, 1.5, 0, None, st) == -1
+    assert lib.dgvit_got_forward(ctypes.byref(cfg), tbl, P(img), P(goal), P(feat), P(ws), n, 2, 1, 1.0, 0, None, st) == 0
     torch.cuda.synchronize()
     assert torch.isfinite(feat).all()
     with pytest.raises(amd.DgvitError, match="img must be"):
@@ -445,3 +445,58 @@ def test_device_replay_buffer(amd):
     m = amd.GoTPolicy(2, 2, 1, 2, 64, image_size=(12, 10), patch_size=(6, 5)).to("cuda").eval()
     mean, _ = m([batch["obs"], batch["pobs"]])
     assert torch.isfinite(mean).all()
+
+
+def test_graphed_training_step(amd):
+    """A whole step (encoder+heads fwd, bwd, FlatAdam capturable, soft update) recorded into a HIP graph must
+    (a) reproduce eager training exactly in eval mode, (b) draw a fresh dropout mask on every replay in train mode."""
+    import copy
+    from dgvit_amd.optim import FlatAdam, flatten_parameters, soft_update
+    cfg = O.GoTConfig(image=(84, 84), patch=(12, 12), dim=64, depth=2, heads=2)
+    kw = dict(image_size=cfg.image, patch_size=cfg.patch)
+    base = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, **kw), O.make_params(O.policy_param_spec(cfg), 61)).to("cuda").eval()
+    img, pstate, _, _ = (t.cuda() for t in O.make_inputs(cfg, 8, 61))
+
+    def make(model):
+        tgt = copy.deepcopy(model)
+        flatten_parameters(tgt)
+        opt = FlatAdam([model], lr=1e-3, capturable=True)
+        flatten_parameters(model) if False else None
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            mean, log_std = model([img, pstate])
+            loss = (mean ** 2).mean() + (log_std ** 2).mean()
+            loss.backward()
+            opt.step()
+            return loss.detach()
+        return step, opt
+
+    ma, mb = copy.deepcopy(base), copy.deepcopy(base)
+    step_a, _ = make(ma)
+    step_b, _ = make(mb)
+    # 3 warm-up steps happen inside GraphedStep; run the same 3 eagerly on the other copy, then 4 more on both
+    g = amd.GraphedStep(step_b, warmup=3)
+    for _ in range(3 + 1):            # warm-up + the capture pass itself does not execute kernels
+        pass
+    for _ in range(3):
+        step_a()
+    for _ in range(4):
+        la = step_a()
+        lb = g()
+    torch.cuda.synchronize()
+    assert abs(la.item() - lb.item()) <= 1e-6 * max(1.0, abs(la.item()))
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
+    # train mode: the captured forward must not freeze the dropout mask
+    mc = copy.deepcopy(base).train()
+    out = {}
+
+    def fwd():
+        with torch.no_grad():
+            out["m"], _ = mc([img, pstate])
+        return out["m"]
+    gf = amd.GraphedStep(fwd, warmup=2)
+    a = gf().clone()
+    b = gf().clone()
+    assert (a - b).abs().max().item() > 1e-4, "dropout mask frozen into the graph"
