@@ -500,3 +500,55 @@ def test_graphed_training_step(amd):
     a = gf().clone()
     b = gf().clone()
     assert (a - b).abs().max().item() > 1e-4, "dropout mask frozen into the graph"
+
+
+def _random_cfgs():
+    rs = np.random.RandomState(1234)
+    out = []
+    for i in range(14):
+        ph, pw = int(rs.choice([2, 3, 4, 5, 6, 7, 8])), int(rs.choice([2, 3, 4, 5, 6, 8, 10]))
+        gh, gw = int(rs.randint(1, 9)), int(rs.randint(1, 9))
+        dim = int(rs.choice([4, 8, 12, 20, 36, 40, 64, 100, 132, 260]))
+        heads = int(rs.choice([1, 2, 3, 5]))
+        dh = int(rs.choice([32, 64]))
+        if dh == 32 and gh * gw + 1 > 64:
+            dh = 64
+        mlp = int(rs.choice([4, 12, 36, 100, 256, 516]))
+        depth = int(rs.choice([1, 2, 3]))
+        batch = int(rs.choice([1, 2, 3, 7, 19]))
+        out.append((O.GoTConfig(image=(gh * ph, gw * pw), patch=(ph, pw), dim=dim, depth=depth, heads=heads, dim_head=dh, mlp_dim=mlp), batch, 900 + i))
+    return out
+
+
+@pytest.mark.parametrize("cfg,batch,seed", _random_cfgs(), ids=lambda v: str(v) if not isinstance(v, O.GoTConfig) else f"{v.image}p{v.patch}D{v.dim}L{v.depth}H{v.heads}x{v.dim_head}M{v.mlp_dim}")
+def test_random_shapes_vs_oracle(amd, cfg, batch, seed):
+    """Property sweep: arbitrary image/patch grids (1..65 tokens), dims that are multiples of 4 but
+    of no tile size, odd head counts and MLP widths, tiny batches -- outputs and every gradient against the oracle,
+    train mode with the HIP dropout mask replayed into the oracle."""
+    params = O.make_params(O.got_param_spec(cfg, prefix=""), seed)
+    m = _load_state(_build_got(amd, cfg), params).train()
+    img, _, _, _ = O.make_inputs(cfg, batch, seed)
+    rs = np.random.RandomState(seed)
+    goal = torch.from_numpy(rs.standard_normal((batch, cfg.dim))).float()
+    wout = torch.from_numpy(rs.standard_normal((batch, cfg.dim))).float()
+    torch.manual_seed(seed)
+    dseed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    torch.manual_seed(seed)
+    gg = goal.cuda().requires_grad_(True)
+    feat = m(img.cuda(), gg)
+    (feat * wout.cuda()).sum().backward()
+    ones = torch.ones(batch * cfg.tokens * cfg.dim, device="cuda")
+    amd.functional.op_dropout_(ones, dseed, 0.9)
+    mask = (ones != 0).float().reshape(batch, cfg.tokens, cfg.dim).cpu()
+    p = {k: v.clone().double().requires_grad_(True) for k, v in params.items()}
+    go = goal.clone().double().requires_grad_(True)
+    ref = O.got_forward(p, img.double(), go, cfg, drop_mask=mask.double(), prefix="")
+    (ref * wout.double()).sum().backward()
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(gg.grad.cpu().numpy(), go.grad.numpy(), rtol=3e-3, atol=3e-4 * max(1.0, go.grad.abs().max().item()))
+    for k, prm in m.named_parameters():
+        if prm.grad is None:
+            assert p[k].grad is None, k
+            continue
+        r = p[k].grad.numpy()
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), r, rtol=3e-3, atol=3e-4 * max(1.0, np.abs(r).max()), err_msg=k)
