@@ -17,7 +17,7 @@ class DgvitError(RuntimeError):
 
 class dgvit_config(Structure):
     _fields_ = [("image_h", c_int), ("image_w", c_int), ("patch_h", c_int), ("patch_w", c_int), ("dim", c_int),
-                ("depth", c_int), ("heads", c_int), ("dim_head", c_int), ("mlp_dim", c_int)]
+                ("depth", c_int), ("heads", c_int), ("dim_head", c_int), ("mlp_dim", c_int), ("pool_mean", c_int)]
 
 
 NUM_GLOBAL_PARAMS = 4

@@ -120,6 +120,16 @@ __global__ void __launch_bounds__(256) avgpool_bwd_relu_kernel(const float* __re
                                                    m.z > 0.f ? g.z * inv : 0.f, m.w > 0.f ? g.w * inv : 0.f);
 }
 
+// dx[(b*S+s)][c] = dfeat[b][c] / S      (gradient of a mean over S rows)
+__global__ void __launch_bounds__(256) mean_bwd_kernel(const float* __restrict__ dfeat, float* __restrict__ dx, long long total, int S,
+                                                       int C) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long long b = idx / C / S;
+  dx[idx] = dfeat[b * C + c] / (float)S;
+}
+
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -160,5 +170,12 @@ int avgpool_bwd_relu(const float* dfeat, const float* x, float* dy, int B, int S
   const long long total4 = (long long)B * S * (C / 4);
   hipLaunchKernelGGL(avgpool_bwd_relu_kernel, dim3(nblk(total4)), dim3(256), 0, st, dfeat, x, dy, total4, S, C);
   DGVIT_CHECK_LAUNCH("avgpool_bwd");
+  return DGVIT_OK;
+}
+
+int mean_bwd(const float* dfeat, float* dx, int B, int S, int C, hipStream_t st) {
+  const long long total = (long long)B * S * C;
+  hipLaunchKernelGGL(mean_bwd_kernel, dim3(nblk(total)), dim3(256), 0, st, dfeat, dx, total, S, C);
+  DGVIT_CHECK_LAUNCH("mean_bwd");
   return DGVIT_OK;
 }

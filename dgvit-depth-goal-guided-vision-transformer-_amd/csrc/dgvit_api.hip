@@ -33,6 +33,7 @@ int weight_pack(const float*, float*, int, int, int, int, hipStream_t);
 int avgpool(const float*, float*, int, int, int, hipStream_t);
 int avgpool_bwd_relu(const float*, const float*, float*, int, int, int, hipStream_t);
 int gather_rows(const float*, const long long*, float*, long long, long long, long long, hipStream_t);
+int mean_bwd(const float*, float*, int, int, int, hipStream_t);
 extern int g_gemm_tile_hint;
 static int g_prune_last = 1;  // last block: only token 0 feeds the output (GoalFormer.py:167)
 static int g_overlap_wgrad = 0;  // opt-in: run weight-gradient GEMMs on a helper stream beside the data-gradient chain
@@ -143,7 +144,7 @@ int wgrad(const float* A, int lda, const float* B, int ldb, float* dW, float* db
 }
 
 struct Dims {
-  int B, P, N, D, I, M, L, H, dh, pd;
+  int B, P, N, D, I, M, L, H, dh, pd, pool_mean;
   long long T;
 };
 
@@ -161,6 +162,7 @@ int make_dims(const dgvit_config* c, int batch, Dims& d) {
   d.N = d.P + 1;
   d.D = c->dim; d.H = c->heads; d.dh = c->dim_head; d.I = d.H * d.dh; d.M = c->mlp_dim; d.L = c->depth;
   d.pd = c->patch_h * c->patch_w;
+  d.pool_mean = c->pool_mean ? 1 : 0;
   d.T = (long long)batch * d.N;
   DGVIT_CHECK_ARG(d.N <= (d.dh == 64 ? 224 : 64), "tokens N=%d exceeds the fused-attention limit", d.N);
   DGVIT_CHECK_ARG(d.T < (1ll << 31) && d.T * (long long)(3 * d.I > d.M ? 3 * d.I : d.M) < (1ll << 40), "batch too large");
@@ -169,7 +171,7 @@ int make_dims(const dgvit_config* c, int batch, Dims& d) {
 
 // activation workspace carve-up (floats); `save` keeps per-layer buffers distinct
 struct Ws {
-  long long patches, x0, layer0, layer_stride, layer_floats, total;
+  long long patches, x0, pooled, layer0, layer_stride, layer_floats, total;
   // per-layer offsets relative to the layer base
   long long mean1, rstd1, ln1, qkv, ao, xmid, mean2, rstd2, ln2, h1, a1, xout;
 };
@@ -179,6 +181,7 @@ Ws make_ws(const Dims& d, int save) {
   long long o = 0;
   w.patches = o; o += al4((long long)d.B * d.P * d.pd);
   w.x0 = o; o += al4(d.T * d.D);
+  w.pooled = o; o += al4((long long)d.B * d.D);   // token mean (pool='mean' only)
   long long l = 0;
   w.mean1 = l; l += al4(d.T);
   w.rstd1 = l; l += al4(d.T);
@@ -306,7 +309,7 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     // The output only reads token 0 of the last block (GoalFormer.py:167): there, K and V are needed for every
     // token but Q, the attention output, to_out and the whole feed-forward only for row b*N of each frame.
     // `tok` = rows processed, `rs` = row step (in token rows) of those rows inside the (T, .) buffers.
-    const bool last = g_prune_last && i == d.L - 1;
+    const bool last = g_prune_last && !d.pool_mean && i == d.L - 1;
     const int tok = last ? d.B : T, rs = last ? d.N : 1;
     // x = attn(LN(x)) + x   (GoalFormer.py:103, 36-37, 71-82)
     TRY(layernorm_fwd(x, lp[L_LN1W], lp[L_LN1B], lb + w.ln1, lb + w.mean1, lb + w.rstd1, T, d.D, 1e-5f, 1, st));
@@ -339,7 +342,12 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     }
     x = xo;
   }
-  // x[:, 0] -> RMSNorm  (GoalFormer.py:167-170)
+  // pool: x[:, 0] (cls slot = goal token) or the token mean (GoalFormer.py:167), then RMSNorm (:170)
+  if (d.pool_mean) {
+    float* pooled = ws + w.pooled;
+    TRY(avgpool(x, pooled, d.B, d.N, d.D, st));
+    return rmsnorm_fwd(pooled, d.D, params[P_RMS], feat, d.B, d.D, st);
+  }
   return rmsnorm_fwd(x, (long long)d.N * d.D, params[P_RMS], feat, d.B, d.D, st);
 }
 
@@ -380,15 +388,21 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
 
   // RMSNorm on token 0 of the last layer's output; every other token row gets zero gradient
   const float* xl = ws + w.layer0 + w.layer_stride * (d.L - 1) + w.xout;
-  HIP_TRY(hipMemsetAsync(dx, 0, sizeof(float) * d.T * d.D, st));
-  TRY(rmsnorm_bwd(dfeat, xl, (long long)d.N * d.D, params[P_RMS], dx, (long long)d.N * d.D, grads[P_RMS], part, d.B, d.D, st));
+  if (d.pool_mean) {
+    // feat = RMSNorm(mean_tokens(x)): gradient of the pooled vector (into dln as scratch), then broadcast / N
+    TRY(rmsnorm_bwd(dfeat, ws + w.pooled, d.D, params[P_RMS], dln, d.D, grads[P_RMS], part, d.B, d.D, st));
+    TRY(mean_bwd(dln, dx, d.B, d.N, d.D, st));
+  } else {
+    HIP_TRY(hipMemsetAsync(dx, 0, sizeof(float) * d.T * d.D, st));
+    TRY(rmsnorm_bwd(dfeat, xl, (long long)d.N * d.D, params[P_RMS], dx, (long long)d.N * d.D, grads[P_RMS], part, d.B, d.D, st));
+  }
 
   for (int i = d.L - 1; i >= 0; --i) {
     const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
     float* const* lg = grads + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
     const float* lb = ws + w.layer0 + w.layer_stride * i;
     const float* xin = i == 0 ? ws + w.x0 : ws + w.layer0 + w.layer_stride * (i - 1) + w.xout;
-    const bool last = g_prune_last && i == d.L - 1;      // see dgvit_got_forward: only rows b*N carry gradient here
+    const bool last = g_prune_last && !d.pool_mean && i == d.L - 1;   // see dgvit_got_forward: only rows b*N carry gradient here
     const int tok = last ? d.B : T, rs = last ? d.N : 1;
     // ---- feed-forward branch: xout = fc2(gelu(fc1(ln2))) + xmid
     // (helper-stream kernels are ordered among themselves, so the slab scratch is reused safely; a `join` before

@@ -8,7 +8,7 @@ fused HIP forward/backward (functional.got_encoder); none of them runs PyTorch m
 Differences from the reference, on purpose:
   * ``patch_size`` is honoured (the reference hard-wires 16x20 / Linear(320, dim), GoalFormer.py:137-139);
     with patch_size=(16, 20) the parameter shapes are identical;
-  * ``pool`` must be 'cls' and transformer ``dropout`` 0 (the only values the reference's nets ever use).
+  * transformer ``dropout`` must be 0 (the only value the reference's nets ever use); ``pool`` 'cls' and 'mean' both work.
 """
 import math
 
@@ -92,8 +92,6 @@ class GoT(nn.Module):
         assert image_height % patch_height == 0 and image_width % patch_width == 0, \
             'Image dimensions must be divisible by the patch size.'
         assert pool in {'cls', 'mean'}, 'pool type must be either cls (cls token) or mean (mean pooling)'
-        if pool != 'cls':
-            raise NotImplementedError("pool='mean' is never used by the reference networks; only 'cls' is built")
         if dropout != 0.:
             raise NotImplementedError("transformer dropout must be 0 (the reference never sets it)")
         num_patches = (image_height // patch_height) * (image_width // patch_width)
@@ -107,7 +105,8 @@ class GoT(nn.Module):
         self.pool = pool
         self.to_latent = nn.Identity()
         self.mlp_head = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, num_classes))  # unused, kept for checkpoints
-        self._cfg = (image_height, image_width, patch_height, patch_width, dim, depth, heads, dim_head, mlp_dim)
+        self._cfg = (image_height, image_width, patch_height, patch_width, dim, depth, heads, dim_head, mlp_dim,
+                     1 if pool == 'mean' else 0)
 
     def param_table(self):
         """Parameters in the order of include/dgvit_hip.h's table."""

@@ -48,6 +48,7 @@ typedef struct dgvit_config {
   int heads;     /* H */
   int dim_head;  /* dh, inner width I = H*dh */
   int mlp_dim;   /* M */
+  int pool_mean; /* 0: pool='cls' (token 0, what the reference's networks use), 1: pool='mean' (GoalFormer.py:167) */
 } dgvit_config;
 
 /* Parameter / gradient tables: arrays of DGVIT_NUM_GLOBAL_PARAMS + DGVIT_PARAMS_PER_LAYER*depth device

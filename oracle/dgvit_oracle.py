@@ -298,14 +298,15 @@ def got_block(p: Dict[str, Tensor], x: Tensor, i: int, cfg: GoTConfig, prefix: s
 
 def got_forward(p: Dict[str, Tensor], img: Tensor, goal: Tensor, cfg: GoTConfig,
                 drop_mask: Optional[Tensor] = None, prefix: str = "trans.",
-                return_tokens: bool = False):
-    """GoT.forward (GoalFormer.py:156-171), pool='cls': token 0 -> RMSNorm."""
+                return_tokens: bool = False, pool: str = "cls"):
+    """GoT.forward (GoalFormer.py:156-171): pool='cls' takes token 0, pool='mean' the token mean (:167) -> RMSNorm."""
     x = got_embed(p, img, goal, cfg, drop_mask, prefix=prefix)
     toks = [x]
     for i in range(cfg.depth):                                                # :165
         x = got_block(p, x, i, cfg, prefix)
         toks.append(x)
-    feat = rms_norm(x[:, 0], p[prefix + "layer_norm.g"])                      # :167-170
+    pooled = x.mean(dim=1) if pool == "mean" else x[:, 0]                       # :167
+    feat = rms_norm(pooled, p[prefix + "layer_norm.g"])                       # :170
     return (feat, toks) if return_tokens else feat
 
 

@@ -58,9 +58,9 @@ def resize_patch_embed(trans, cfg):
         nn.Linear(ph * pw, cfg.dim))
 
 
-def build_got(cfg):
+def build_got(cfg, pool='cls'):
     m = ref_gf.GoT(image_size=cfg.image, patch_size=cfg.patch, num_classes=cfg.num_classes, dim=cfg.dim,
-                   depth=cfg.depth, heads=cfg.heads, mlp_dim=cfg.mlp_dim, channels=1, dim_head=cfg.dim_head)
+                   depth=cfg.depth, heads=cfg.heads, mlp_dim=cfg.mlp_dim, channels=1, dim_head=cfg.dim_head, pool=pool)
     if tuple(cfg.patch) != (16, 20):
         resize_patch_embed(m, cfg)
     return m
@@ -108,9 +108,9 @@ def cfg_meta(cfg, batch, seed):
             "meta/batch": np.array(batch), "meta/seed": np.array(seed)}
 
 
-def case_got(name, cfg, batch, seed, with_mask=False, full_grads=False):
+def case_got(name, cfg, batch, seed, with_mask=False, full_grads=False, pool='cls'):
     """Bare GoT encoder: features, per-layer token-0 rows, gradients of sum(feat * w)."""
-    m = build_got(cfg)
+    m = build_got(cfg, pool)
     load(m, O.got_param_spec(cfg, prefix=""), seed)
     img, _, _, _ = O.make_inputs(cfg, batch, seed)
     rs = np.random.RandomState(seed + 7)
@@ -234,6 +234,7 @@ def main():
     tiny = C(image=(16, 24), patch=(8, 8), dim=32, depth=2, heads=2, dim_head=32, mlp_dim=64)
     case_got("got_tiny_eval", tiny, 3, 0, full_grads=True)
     case_got("got_tiny_mask", tiny, 3, 1, with_mask=True, full_grads=True)
+    case_got("got_tiny_meanpool", tiny, 3, 2, full_grads=True, pool='mean')
     # patch sizes BASELINE leaves open for 84x84 (N = 50 / 37 / 145 / 197), small width
     for ps in (12, 14, 7, 6):
         case_got(f"got_84p{ps}", C(image=(84, 84), patch=(ps, ps), dim=64, depth=1, heads=2), 2, 10 + ps)

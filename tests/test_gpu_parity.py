@@ -552,3 +552,22 @@ def test_random_shapes_vs_oracle(amd, cfg, batch, seed):
             continue
         r = p[k].grad.numpy()
         np.testing.assert_allclose(prm.grad.cpu().numpy(), r, rtol=3e-3, atol=3e-4 * max(1.0, np.abs(r).max()), err_msg=k)
+
+
+def test_got_meanpool_golden(amd):
+    """GoT(pool='mean') through the HIP path vs the reference (dense last block, token-mean, broadcast gradient)."""
+    fx = load_fixture("got_tiny_meanpool")
+    cfg = fixture_cfg(fx)
+    m = amd.GoT(image_size=cfg.image, patch_size=cfg.patch, num_classes=2, dim=cfg.dim, depth=cfg.depth, heads=cfg.heads,
+                mlp_dim=cfg.mlp_dim, channels=1, dim_head=cfg.dim_head, pool='mean')
+    m = _load_state(m, O.make_params(O.got_param_spec(cfg, prefix=""), int(fx["meta/seed"]))).eval()
+    img, goal, wout, _ = got_case_inputs(fx, cfg, False)
+    goal = goal.cuda().requires_grad_(True)
+    feat = m(img.cuda(), goal)
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), fx["feat"], rtol=0, atol=OUT_TOL)
+    (feat * wout.cuda()).sum().backward()
+    np.testing.assert_allclose(goal.grad.cpu().numpy(), fx["dgoal"], rtol=GRAD_RTOL, atol=1e-4)
+    for k, p in m.named_parameters():
+        if f"gfull/{k}" in fx:
+            ref = fx[f"gfull/{k}"]
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=GRAD_RTOL, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k)

@@ -142,3 +142,19 @@ def test_cnn_cases(name, kind):
     np.testing.assert_allclose(loss.item(), float(fx["loss"]), rtol=1e-5)
     loss.backward()
     check_grad_digest(fx, "g", {k: v.grad for k, v in p.items()}, rtol=5e-4, atol=2e-6)
+
+
+def test_got_meanpool_case():
+    """pool='mean' (GoalFormer.py:167) against the reference."""
+    fx = load_fixture("got_tiny_meanpool")
+    cfg = fixture_cfg(fx)
+    p = _leaf_params(O.got_param_spec(cfg, prefix=""), int(fx["meta/seed"]))
+    img, goal, wout, _ = got_case_inputs(fx, cfg, False)
+    goal.requires_grad_(True)
+    feat = O.got_forward(p, img, goal, cfg, prefix="", pool="mean")
+    np.testing.assert_allclose(feat.detach().numpy(), fx["feat"], rtol=0, atol=TOL)
+    (feat * wout).sum().backward()
+    np.testing.assert_allclose(goal.grad.numpy(), fx["dgoal"], rtol=1e-4, atol=1e-5)
+    for k, v in p.items():
+        if f"gfull/{k}" in fx:
+            np.testing.assert_allclose(v.grad.numpy(), fx[f"gfull/{k}"], rtol=1e-4, atol=2e-5, err_msg=k)
