@@ -51,8 +51,8 @@ SIGNATURES = {
     "dgvit_rmsnorm_forward": (_I, [_P, _LL, _P, _P, _I, _I, _P]),
     "dgvit_rmsnorm_backward_scratch_floats": (_LL, [_I, _I]),
     "dgvit_rmsnorm_backward": (_I, [_P, _P, _LL, _P, _P, _LL, _P, _P, _LL, _I, _I, _P]),
-    "dgvit_attention_forward": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "dgvit_attention_backward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dgvit_attention_forward": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dgvit_attention_backward": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dgvit_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dgvit_dropout": (_I, [_P, _LL, _ULL, _F, _P]),
     "dgvit_cnn_workspace_floats": (_LL, [_I, _I, _I]),

@@ -18,8 +18,8 @@ int rmsnorm_bwd_blocks(int B);
 int rmsnorm_bwd(const float*, const float*, long long, const float*, float*, long long, float*, float*, int, int, hipStream_t);
 int colsum_blocks(int T);
 int colsum(const float*, long long, float*, float*, int, int, int, hipStream_t);
-int attention_fwd(const float*, float*, int, int, int, int, int, hipStream_t);
-int attention_bwd(const float*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+int attention_fwd(const float*, float*, float*, int, int, int, int, int, hipStream_t);
+int attention_bwd(const float*, const float*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 int patchify(const float*, float*, int, int, int, int, int, hipStream_t);
 int goal_row(const float*, const float*, float*, int, int, int, hipStream_t);
 int dropout_inplace(float*, long long, unsigned long long, const unsigned long long*, float, hipStream_t);
@@ -164,7 +164,7 @@ int make_dims(const dgvit_config* c, int batch, Dims& d) {
   d.pd = c->patch_h * c->patch_w;
   d.pool_mean = c->pool_mean ? 1 : 0;
   d.T = (long long)batch * d.N;
-  DGVIT_CHECK_ARG(d.N <= (d.dh == 64 ? 224 : 64), "tokens N=%d exceeds the fused-attention limit", d.N);
+  DGVIT_CHECK_ARG(d.N <= 224, "tokens N=%d exceeds the fused-attention limit (224)", d.N);
   DGVIT_CHECK_ARG(d.T < (1ll << 31) && d.T * (long long)(3 * d.I > d.M ? 3 * d.I : d.M) < (1ll << 40), "batch too large");
   return DGVIT_OK;
 }
@@ -173,7 +173,7 @@ int make_dims(const dgvit_config* c, int batch, Dims& d) {
 struct Ws {
   long long patches, x0, pooled, layer0, layer_stride, layer_floats, total;
   // per-layer offsets relative to the layer base
-  long long mean1, rstd1, ln1, qkv, ao, xmid, mean2, rstd2, ln2, h1, a1, xout;
+  long long mean1, rstd1, ln1, qkv, ao, lse, xmid, mean2, rstd2, ln2, h1, a1, xout;
 };
 
 Ws make_ws(const Dims& d, int save) {
@@ -188,6 +188,7 @@ Ws make_ws(const Dims& d, int save) {
   w.ln1 = l; l += al4(d.T * d.D);
   w.qkv = l; l += al4(d.T * 3 * d.I);
   w.ao = l; l += al4(d.T * d.I);
+  w.lse = l; l += al4((long long)d.B * d.H * d.N);   // base-2 log-sum-exp of every attention row
   w.xmid = l; l += al4(d.T * d.D);
   w.mean2 = l; l += al4(d.T);
   w.rstd2 = l; l += al4(d.T);
@@ -322,7 +323,7 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
       GemmParams q = gp(lb + w.ln1, rs * d.D, lp[L_QKV], d.D, lb + w.qkv, rs * 3 * d.I, tok, d.I, d.D);
       TRY(gemm_f32(GEMM_NT, EPI_STORE, q, 1, st));
     }
-    TRY(attention_fwd(lb + w.qkv, lb + w.ao, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
+    TRY(attention_fwd(lb + w.qkv, lb + w.ao, save ? lb + w.lse : nullptr, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
     {
       GemmParams p = gp(lb + w.ao, rs * d.I, lp[L_OUTW], d.I, lb + w.xmid, rs * d.D, tok, d.D, d.I);
       p.bias = lp[L_OUTB]; p.res = x; p.ldr = rs * d.D;
@@ -429,7 +430,7 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
       GemmParams p = gp(dx2, rs * d.D, lp[L_OUTW], d.I, dao, rs * d.I, tok, d.I, d.D);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dao = dxmid Wo
     }
-    TRY(attention_bwd(lb + w.qkv, lb + w.ao, dao, dqkv, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
+    TRY(attention_bwd(lb + w.qkv, lb + w.ao, dao, lb + w.lse, dqkv, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
     TRY(fork());
     if (!last) {
       TRY(wgrad(dqkv, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV], nullptr, 3 * d.I, d.D, T, slabs, s.slabs_floats, sw));
@@ -557,12 +558,12 @@ extern "C" int dgvit_rmsnorm_backward(const float* dy, const float* x, long long
     return dgvit_set_error(DGVIT_ERR_WORKSPACE, "rmsnorm_backward: scratch too small");
   return rmsnorm_bwd(dy, x, ldx, g, dx, lddx, dg, scratch, rows, D, (hipStream_t)stream);
 }
-extern "C" int dgvit_attention_forward(const float* qkv, float* out, int B, int N, int H, int dh, void* stream) {
-  return attention_fwd(qkv, out, B, N, H, dh, N, (hipStream_t)stream);
+extern "C" int dgvit_attention_forward(const float* qkv, float* out, float* lse, int B, int N, int H, int dh, void* stream) {
+  return attention_fwd(qkv, out, lse, B, N, H, dh, N, (hipStream_t)stream);
 }
-extern "C" int dgvit_attention_backward(const float* qkv, const float* out, const float* dout, float* dqkv, int B, int N, int H,
-                                        int dh, void* stream) {
-  return attention_bwd(qkv, out, dout, dqkv, B, N, H, dh, N, (hipStream_t)stream);
+extern "C" int dgvit_attention_backward(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                                        int B, int N, int H, int dh, void* stream) {
+  return attention_bwd(qkv, out, dout, lse, dqkv, B, N, H, dh, N, (hipStream_t)stream);
 }
 extern "C" int dgvit_patchify(const float* img, float* patches, int B, int ih, int iw, int ph, int pw, void* stream) {
   return patchify(img, patches, B, ih, iw, ph, pw, (hipStream_t)stream);

@@ -269,16 +269,18 @@ def op_attention_fwd(qkv, heads, dim_head):
     B, N, W = qkv.shape
     assert W == 3 * heads * dim_head
     out = torch.empty(B, N, heads * dim_head, dtype=torch.float32, device=qkv.device)
-    _lib.check(lib.dgvit_attention_forward(_ptr(qkv), _ptr(out), B, N, heads, dim_head, _stream()), "dgvit_attention_forward")
-    return out
+    lse = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device)
+    _lib.check(lib.dgvit_attention_forward(_ptr(qkv), _ptr(out), _ptr(lse), B, N, heads, dim_head, _stream()),
+               "dgvit_attention_forward")
+    return out, lse
 
 
-def op_attention_bwd(qkv, out, dout, heads, dim_head):
+def op_attention_bwd(qkv, out, dout, lse, heads, dim_head):
     lib = _lib.load()
     B, N, _ = qkv.shape
     dqkv = torch.empty_like(qkv)
-    _lib.check(lib.dgvit_attention_backward(_ptr(qkv), _ptr(out), _ptr(_dev(dout, "dout")), _ptr(dqkv), B, N, heads, dim_head,
-                                            _stream()), "dgvit_attention_backward")
+    _lib.check(lib.dgvit_attention_backward(_ptr(qkv), _ptr(out), _ptr(_dev(dout, "dout")), _ptr(lse), _ptr(dqkv), B, N, heads,
+                                            dim_head, _stream()), "dgvit_attention_backward")
     return dqkv
 
 

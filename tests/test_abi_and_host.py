@@ -48,7 +48,7 @@ def test_size_queries_and_validation_without_gpu(amd):
     assert train > infer > 0
     # per layer: ln1, xmid, ln2, xout (T*D each) + qkv (3I) + ao (I) + h1, a1 (M each) + 4 stat rows
     T, D, I, M = 512 * 50, 256, 512, 2048
-    per_layer = T * (4 * D + 4 * I + 2 * M + 4)
+    per_layer = T * (4 * D + 4 * I + 2 * M + 4) + 512 * 8 * 50
     assert train >= 6 * per_layer
     assert lib.dgvit_got_backward_scratch_floats(ctypes.byref(cfg), 512) > T * M
     # reference assertion text for indivisible images (GoalFormer.py:131)

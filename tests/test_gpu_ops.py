@@ -138,16 +138,20 @@ def _attn_ref(qkv, H, dh):
 
 
 @pytest.mark.parametrize("B,N,H,dh", [(3, 50, 8, 64), (2, 65, 4, 64), (2, 7, 2, 32), (1, 32, 1, 64), (2, 37, 2, 64), (1, 145, 2, 64),
-                                      (1, 197, 3, 64), (2, 64, 2, 32), (1, 1, 2, 64), (1, 224, 1, 64)])
+                                      (1, 197, 3, 64), (2, 64, 2, 32), (1, 1, 2, 64), (1, 224, 1, 64), (2, 100, 3, 32), (1, 96, 2, 64)])
 def test_attention_fwd_bwd(F, B, N, H, dh):
     qkv = rnd(B, N, 3 * H * dh, seed=N)
     dout = rnd(B, N, H * dh, seed=N + 1)
     qr = qkv.clone().requires_grad_(True)
     ref = _attn_ref(qr, H, dh)
     ref.backward(dout)
-    out = F.op_attention_fwd(dev(qkv), H, dh)
+    out, lse = F.op_attention_fwd(dev(qkv), H, dh)
     close(out, ref.detach(), atol=2e-5)
-    dqkv = F.op_attention_bwd(dev(qkv), out, dev(dout), H, dh)
+    I = H * dh
+    q, k = (qkv[..., j * I:(j + 1) * I].reshape(B, N, H, dh).permute(0, 2, 1, 3) for j in range(2))
+    lse_ref = torch.logsumexp((q @ k.transpose(-1, -2)) * dh ** -0.5, -1) / math.log(2.0)     # base-2 units
+    close(lse, lse_ref, atol=2e-5)
+    dqkv = F.op_attention_bwd(dev(qkv), out, dev(dout), lse, H, dh)
     close(dqkv, qr.grad, atol=1e-4)
 
 
@@ -156,7 +160,7 @@ def test_attention_peaked_softmax(F):
     B, N, H, dh = 1, 50, 2, 64
     qkv = rnd(B, N, 3 * H * dh, seed=3) * 6.0
     ref = _attn_ref(qkv, H, dh)
-    close(F.op_attention_fwd(dev(qkv), H, dh), ref, atol=5e-4)
+    close(F.op_attention_fwd(dev(qkv), H, dh)[0], ref, atol=5e-4)
 
 
 # ---------------------------------------------------------------- token assembly pieces

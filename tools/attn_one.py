@@ -9,6 +9,6 @@ B, N, H, dh = 512, int(os.environ.get("N", 50)), 8, 64
 qkv = torch.randn(B, N, 3 * H * dh, device="cuda")
 dout = torch.randn(B, N, H * dh, device="cuda")
 for _ in range(4):
-    out = F.op_attention_fwd(qkv, H, dh)
-    dq = F.op_attention_bwd(qkv, out, dout, H, dh)
+    out, lse = F.op_attention_fwd(qkv, H, dh)
+    dq = F.op_attention_bwd(qkv, out, dout, lse, H, dh)
 torch.cuda.synchronize()
