@@ -17,6 +17,7 @@
 //   phase 2 (wave = key tile, Q/dO in LDS):   P = exp2(S - lse), dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
 // with delta[q] = sum_d dO[q][d] O[q][d].  Register use is independent of N (occupancy 2+ waves/SIMD for every N).
 #include "common.h"
+#include "kernels.h"
 
 namespace {
 
@@ -318,8 +319,8 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_bwd_kernel(const float* __res
     f32x16 dk[DT], dv[DT];
     zero_tiles<DT>(dk);
     zero_tiles<DT>(dv);
-#pragma unroll NKT_CT ? 2 : 1
-    for (int qt = 0; qt < (NKT_CT ? min(nqt, NKT_CT) : nqt); ++qt) {
+#pragma unroll 1
+    for (int qt = 0; qt < nqt; ++qt) {
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

@@ -9,6 +9,7 @@
 // col2im (each input pixel sums the <= 9 windows that cover it: deterministic, no atomics) with the previous
 // layer's ReLU mask fused.  The single-channel first layer pads K = 25 to 28 so that it takes the float4 path.
 #include "common.h"
+#include "kernels.h"
 
 namespace {
 

@@ -5,6 +5,7 @@
 //                   -- the same call with the same seed re-creates the mask in backward, nothing is stored
 //   relu_bwd      : dpre = dy * (y > 0)                    (head MLPs)
 #include "common.h"
+#include "kernels.h"
 
 namespace {
 

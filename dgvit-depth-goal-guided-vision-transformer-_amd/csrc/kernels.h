@@ -1,0 +1,31 @@
+// Internal prototypes of the launch functions implemented in the kernel translation units
+// (norm.hip, attention.hip, embed.hip, conv.hip, optim.hip, gemm.hip); the schedules in dgvit_api.hip call these.
+#pragma once
+#include "common.h"
+
+int layernorm_fwd(const float*, const float*, const float*, float*, float*, float*, int, int, float, int, hipStream_t);
+int layernorm_bwd_blocks(int T);
+int layernorm_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*,
+                  float*, int, int, int, hipStream_t);
+int rmsnorm_fwd(const float*, long long, const float*, float*, int, int, hipStream_t);
+int rmsnorm_bwd_blocks(int B);
+int rmsnorm_bwd(const float*, const float*, long long, const float*, float*, long long, float*, float*, int, int, hipStream_t);
+int colsum_blocks(int T);
+int colsum(const float*, long long, float*, float*, int, int, int, hipStream_t);
+int attention_fwd(const float*, float*, float*, int, int, int, int, int, hipStream_t);
+int attention_bwd(const float*, const float*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+int patchify(const float*, float*, int, int, int, int, int, hipStream_t);
+int goal_row(const float*, const float*, float*, int, int, int, hipStream_t);
+int dropout_inplace(float*, long long, unsigned long long, const unsigned long long*, float, hipStream_t);
+int relu_bwd(const float*, const float*, float*, long long, hipStream_t);
+int adam_step(float*, const float*, float*, float*, long long, float, float, float, float, float, long long, const long long*,
+              hipStream_t);
+int soft_update(float*, const float*, long long, float, hipStream_t);
+int im2col(const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+int col2im_relu(const float*, const float*, float*, int, int, int, int, int, int, hipStream_t);
+int weight_pack(const float*, float*, int, int, int, int, hipStream_t);
+int avgpool(const float*, float*, int, int, int, hipStream_t);
+int avgpool_bwd_relu(const float*, const float*, float*, int, int, int, hipStream_t);
+int gather_rows(const float*, const long long*, float*, long long, long long, long long, hipStream_t);
+int mean_bwd(const float*, float*, int, int, int, hipStream_t);
+extern int g_gemm_tile_hint;

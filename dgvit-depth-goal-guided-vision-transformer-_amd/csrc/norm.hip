@@ -5,6 +5,7 @@
 // Column reductions (dgamma/dbeta/dg/db) are two-stage and deterministic: every workgroup writes one
 // partial row into a slab, reduce_slabs() adds the slabs in a fixed order.
 #include "common.h"
+#include "kernels.h"
 
 namespace {
 

@@ -5,6 +5,7 @@
 //   soft_update : target <- target * (1 - tau) + source * tau
 // Algorithmic bytes: Adam 28 B/parameter (read p,g,m,v; write p,m,v), soft update 12 B/parameter.
 #include "common.h"
+#include "kernels.h"
 
 namespace {
 
