@@ -25,9 +25,11 @@
 
 namespace {
 
-template <int BM_, int BN_, int BK_>
+// BM x BN output tile, BK-deep k-tiles, WVM x WVN waves (each owning a (BM/WVM) x (BN/WVN) block of 32x32 accumulators).
+// 2x2 waves everywhere: two-wave workgroups (1x2 / 2x1) measured 10-45 % slower (tools/gemm_fill_probe.py, round 1)
+template <int BM_, int BN_, int BK_, int WVM_ = 2, int WVN_ = 2>
 struct TileCfg {
-  static constexpr int BM = BM_, BN = BN_, BK = BK_;
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WVM = WVM_, WVN = WVN_, NT = 64 * WVM_ * WVN_;
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {
@@ -46,9 +48,10 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define DGVIT_OOB 0xFFFFFFF0u
 
-template <int R, int BK, bool KC, int VEC>
+template <int R, int BK, bool KC, int VEC, int NT>
 struct Fetch {
-  static constexpr int NV = R * BK / 4 / 256;  // float4 slots per thread
+  static_assert(R * BK / 4 % NT == 0, "tile must split evenly over the workgroup's threads");
+  static constexpr int NV = R * BK / 4 / NT;  // float4 slots per thread
   static constexpr int PER_ROW = KC ? BK / 4 : R / 4;
 
   // --- VEC == 4 ---------------------------------------------------------------------------------
@@ -78,7 +81,7 @@ struct Fetch {
     pl.kstep = KC ? BK * 4u : (unsigned)BK * (unsigned)ld * 4u;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid + i * 256;
+      const int f = tid + i * NT;
       const int a = f / PER_ROW, c = (f % PER_ROW) * 4;
       if (KC) {
         pl.off[i] = ((unsigned)a * (unsigned)ld + (unsigned)c) * 4u;
@@ -107,7 +110,7 @@ struct Fetch {
                                              int rmax, int k0, int kend, int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid + i * 256;
+      const int f = tid + i * NT;
       const int a = f / PER_ROW, c = (f % PER_ROW) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (KC) {
@@ -137,7 +140,7 @@ struct Fetch {
     constexpr int STRIDE = KC ? BK + 4 : R + 4;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int f = tid + i * 256;
+      const int f = tid + i * NT;
       const int a = f / PER_ROW, c = (f % PER_ROW) * 4;
       *reinterpret_cast<float4*>(lds + a * STRIDE + c) = reg[i];
     }
@@ -192,22 +195,23 @@ __device__ __forceinline__ void sched_pattern() {
 #undef SGB
 
 template <class T, int LAYOUT, int VEC, int EPI>
-__global__ void __launch_bounds__(256, 2) gemm_f32_kernel(const GemmParams p) {
-  constexpr int BM = T::BM, BN = T::BN, BK = T::BK;
+__global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) {
+  constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NT;
   constexpr bool AKC = LAYOUT != GEMM_TN;
   constexpr bool BKC = LAYOUT == GEMM_NT;
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int WM = BM / T::WVM, WN = BN / T::WVN, TM = WM / 32, TN = WN / 32;
+  static_assert(WM % 32 == 0 && WN % 32 == 0 && BM <= NT, "bad wave layout");
   constexpr int A_TILE = AKC ? BM * (BK + 4) : BK * (BM + 4);
   constexpr int B_TILE = BKC ? BN * (BK + 4) : BK * (BN + 4);
   constexpr int STAGE = A_TILE + B_TILE;
-  using FA = Fetch<BM, BK, AKC, VEC>;
-  using FB = Fetch<BN, BK, BKC, VEC>;
+  using FA = Fetch<BM, BK, AKC, VEC, NT>;
+  using FB = Fetch<BN, BK, BKC, VEC, NT>;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / T::WVN, wn = wave % T::WVN;
 
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -330,10 +334,10 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(const GemmParams p) {
   }
   // accumulator (col = lane&31, row = (r&3) + 8*(r>>2) + 4*h) -> LDS C image [rows][BN+4] -> float4 rows
   constexpr int CS = BN + 4;
-  constexpr int NCHUNK = (BM * CS <= 2 * STAGE) ? 1 : 2;
+  constexpr int NCHUNK = (BM * CS <= 2 * STAGE) ? 1 : T::WVM;   // whole tile at once, or one wave-row of the tile at a time
   constexpr int CROWS = BM / NCHUNK;
   static_assert(CROWS * CS <= 2 * STAGE && (NCHUNK == 1 || CROWS == WM), "epilogue C image does not fit the staging LDS");
-  constexpr int C4 = BN / 4, RPP = 256 / C4;
+  constexpr int C4 = BN / 4, RPP = NT / C4;
   const int cc = (tid % C4) * 4, rr0 = tid / C4;
   const int n = n0 + cc;
   float bias4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -487,7 +491,7 @@ int launch(const GemmParams& p, int nsplit, hipStream_t stream) {
   DGVIT_CHECK_ARG(tiles > 0 && tiles < (1ll << 31), "gemm: bad tile count %lld", tiles);
   dim3 grid((unsigned)tiles, 1, (unsigned)nsplit);
   const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, stream);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(kern, grid, dim3(T::NT), lds, stream, p);
   profile_end(slot, stream);
   DGVIT_CHECK_LAUNCH("gemm_f32_kernel");
   return DGVIT_OK;

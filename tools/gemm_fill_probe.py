@@ -21,13 +21,13 @@ def timeit(layout, m, n, k, hint, reps=5, inner=5):
         if r: ts.append(s.elapsed_time(e) / inner)
     lib.dgvit_set_gemm_tile(0)
     ts.sort(); return ts[len(ts)//2]
-import itertools
-for (bm, bn, bk) in [(128,128,32),(128,128,16),(64,64,32),(64,64,64),(128,64,32),(64,128,32),(128,64,16),(64,128,16)]:
-    hint = bm*1000000 + bn*1000 + bk
+CFGS = [("128x128x32", 128128032, 128, 128), ("128x128x16", 128128016, 128, 128), ("64x64x32", 64064032, 64, 64),
+        ("64x128x32", 64128032, 64, 128), ("64x128x16", 64128016, 64, 128), ("128x64x32", 128064032, 128, 64)]
+for name, hint, bm, bn in CFGS:
     for K in (256, 2048):
         for per_cu in (2, 8):
             tiles = 256 * per_cu
             m, n = tiles * bm, bn
             ms = timeit(0, m, n, K, hint)
             tf = 2.0 * m * n * K / ms / 1e9
-            print(f"tile {bm:3d}x{bn:3d}x{bk:2d} K={K:4d} wg/CU={per_cu} ({tiles} tiles)  {ms*1e3:8.1f} us  {tf:6.1f} TF  ({tf/157.3*100:4.1f}% of peak)", flush=True)
+            print(f"tile {name:12s} K={K:4d} wg/CU={per_cu:2d} ({tiles} tiles)  {ms*1e3:8.1f} us  {tf:6.1f} TF  ({tf/157.3*100:4.1f}% of peak)", flush=True)
