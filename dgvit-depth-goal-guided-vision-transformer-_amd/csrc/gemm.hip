@@ -26,7 +26,8 @@
 namespace {
 
 // BM x BN output tile, BK-deep k-tiles, WVM x WVN waves (each owning a (BM/WVM) x (BN/WVN) block of 32x32 accumulators).
-// 2x2 waves everywhere: two-wave workgroups (1x2 / 2x1) measured 10-45 % slower (tools/gemm_fill_probe.py, round 1)
+// 2x2 waves everywhere: two-wave workgroups (1x2 / 2x1) measured 10-45 % slower and eight-wave ones (128x128 as 2x4,
+// 256x128x16 as 4x2) hit the same 83 % in-CU ceiling as 2x2 (tools/gemm_fill_probe.py, round 1)
 template <int BM_, int BN_, int BK_, int WVM_ = 2, int WVN_ = 2>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WVM = WVM_, WVN = WVN_, NT = 64 * WVM_ * WVN_;
