@@ -97,13 +97,27 @@ __global__ void __launch_bounds__(256) weight_pack_kernel(const float* __restric
   else dst[idx] = src[ref];
 }
 
-// feat[b][c] = mean over S rows of x[(b*S + s)][c]      (AdaptiveAvgPool2d(1) on NHWC rows)
+// feat[b][c] = mean over S rows of x[(b*S + s)][c]      (AdaptiveAvgPool2d(1) on NHWC rows; token mean of GoT pool='mean')
+// 256 threads = 64 channels x 4 row lanes, 4 independent loads in flight per thread, fixed-order LDS combine.
 __global__ void __launch_bounds__(256) avgpool_kernel(const float* __restrict__ x, float* __restrict__ feat, int S, int C) {
-  const int b = blockIdx.x, c = threadIdx.x + blockIdx.y * 256;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int i = 0; i < S; ++i) s += x[((long long)b * S + i) * C + c];
-  feat[(long long)b * C + c] = s / (float)S;
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int b = blockIdx.x, c = blockIdx.y * 64 + tx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    const float* base = x + (long long)b * S * C + c;
+    int i = ty;
+    for (; i + 12 < S; i += 16) {
+      s0 += base[(long long)i * C];
+      s1 += base[(long long)(i + 4) * C];
+      s2 += base[(long long)(i + 8) * C];
+      s3 += base[(long long)(i + 12) * C];
+    }
+    for (; i < S; i += 4) s0 += base[(long long)i * C];
+  }
+  part[ty][tx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ty == 0 && c < C) feat[(long long)b * C + c] = (((part[0][tx] + part[1][tx]) + part[2][tx]) + part[3][tx]) / (float)S;
 }
 
 // dy[(b*S+s)][c] = x > 0 ? dfeat[b][c] / S : 0
@@ -161,7 +175,7 @@ int weight_pack(const float* src, float* dst, int cout, int cin, int KP, int unp
 }
 
 int avgpool(const float* x, float* feat, int B, int S, int C, hipStream_t st) {
-  hipLaunchKernelGGL(avgpool_kernel, dim3(B, (C + 255) / 256), dim3(256), 0, st, x, feat, S, C);
+  hipLaunchKernelGGL(avgpool_kernel, dim3(B, (C + 63) / 64), dim3(256), 0, st, x, feat, S, C);
   DGVIT_CHECK_LAUNCH("avgpool");
   return DGVIT_OK;
 }
