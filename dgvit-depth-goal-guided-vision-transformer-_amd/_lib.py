@@ -22,7 +22,7 @@ class dgvit_config(Structure):
 
 NUM_GLOBAL_PARAMS = 4
 PARAMS_PER_LAYER = 11
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _P, _I, _LL, _F, _ULL = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 _CFG = POINTER(dgvit_config)
@@ -63,6 +63,15 @@ SIGNATURES = {
     "dgvit_gather_rows": (_I, [_P, _P, _P, _LL, _LL, _LL, _P]),
     "dgvit_adam_step": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _F, _LL, _P, _P]),
     "dgvit_soft_update": (_I, [_P, _P, _LL, _F, _P]),
+    "dgvit_got_bf16_weight_elems": (_LL, [_CFG]),
+    "dgvit_got_pack_weights_bf16": (_I, [_CFG, _TABLE, _P, _LL, _P]),
+    "dgvit_got_bf16_workspace_bytes": (_LL, [_CFG, _I, _I]),
+    "dgvit_got_forward_bf16": (_I, [_CFG, _TABLE, _P, _P, _P, _P, _P, _LL, _I, _I, _F, _ULL, _P, _P]),
+    "dgvit_cast_f32_bf16": (_I, [_P, _P, _LL, _P]),
+    "dgvit_gemm_bf16": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
+    "dgvit_set_gemm_bf16_tile": (None, [_I]),
+    "dgvit_layernorm_forward_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "dgvit_attention_forward_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dgvit_profile_start": (_I, [_I]),
     "dgvit_profile_stop": (_I, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_longlong)]),
 }

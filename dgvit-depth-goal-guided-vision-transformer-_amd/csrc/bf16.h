@@ -1,0 +1,43 @@
+// bf16-storage / fp32-accumulate kernels of the DGViT encoder (BASELINE config 5: 224x224 ViT-Base variant).
+// Internal declarations; the public C ABI is include/dgvit_hip.h.
+#pragma once
+#include "common.h"
+
+typedef unsigned short bf16_t;   // raw bf16 bits in memory
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float fx4 __attribute__((ext_vector_type(4)));
+
+// C = A B^T with A (M,K) and B (N,K) bf16, k contiguous (the forward `Y = X W^T` shape; the backward GEMMs are
+// brought into this shape by transposed bf16 copies of their operands), fp32 accumulate on v_mfma_f32_32x32x16_bf16.
+enum GemmBf16Epilogue {
+  BEPI_BF16 = 0,       // C (bf16) = acc + bias
+  BEPI_GELU_BF16 = 1,  // C (bf16) = gelu_erf(acc + bias);  C2 (bf16, optional) = acc + bias (pre-activation, training)
+  BEPI_F32 = 2,        // C (fp32) = acc + bias + res       (residual stream stays fp32)
+  BEPI_DGELU_BF16 = 3, // C (bf16) = acc * gelu'(aux)       aux (bf16) = saved pre-activation
+  BEPI_F32_PLAIN = 4   // C (fp32) = acc                    (weight gradients)
+};
+
+struct GemmBf16Params {
+  const bf16_t* A; int lda;
+  const bf16_t* B; int ldb;
+  int M, N, K;
+  void* C; int ldc;
+  const float* bias;            // [N] fp32 or null
+  const float* res; int ldr;    // fp32 residual or null
+  int res_mod;                  // > 0: residual row = (m % res_mod) + 1 (positional embedding)
+  int c_rgrp;                   // > 0: physical C row = m + m / c_rgrp + 1 (patch rows -> token rows)
+  bf16_t* C2; int ldc2;         // BEPI_GELU_BF16: pre-activation copy (may be null)
+  const bf16_t* aux; int ldaux; // BEPI_DGELU_BF16
+};
+
+int gemm_bf16(int epi, const GemmBf16Params& p, hipStream_t st);
+extern int g_gemm_bf16_tile_hint;
+
+int cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t st);
+int patchify_bf16(const float* img, bf16_t* patches, int B, int ih, int iw, int ph, int pw, hipStream_t st);
+int layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int T, int D,
+                       float eps, int rs, hipStream_t st);
+int attention_fwd_bf16(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N, int H, int dh, int nq, hipStream_t st);
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }

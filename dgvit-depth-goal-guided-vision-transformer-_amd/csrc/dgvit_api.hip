@@ -672,3 +672,211 @@ extern "C" int dgvit_gather_rows(const float* src, const long long* idx, float* 
                                  long long nrows, void* stream) {
   return gather_rows(src, idx, out, nsel, row_floats, nrows, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------- bf16 configuration
+// BASELINE config 5 (224x224, ViT-Base variant, bf16): bf16 storage for GEMM operands (LayerNorm output, qkv,
+// attention output, MLP hidden, weights), fp32 residual stream / LayerNorm statistics / biases / softmax, fp32
+// accumulation on v_mfma_f32_32x32x16_bf16.  Same schedule as dgvit_got_forward (GoalFormer.py:156-171).
+#include "bf16.h"
+
+namespace {
+
+inline long long al128(long long bytes) { return (bytes + 255) & ~255ll; }
+
+// bf16 weight arena (elements): patch weight, then per layer to_qkv, to_out, fc1, fc2 in the reference's (out, in) layouts
+struct Wp {
+  long long patch, layer0, qkv, out, fc1, fc2, layer_elems, total;
+};
+Wp make_wp(const Dims& d) {
+  Wp w;
+  long long o = 0;
+  w.patch = o; o += al4((long long)d.D * d.pd);
+  long long l = 0;
+  w.qkv = l; l += (long long)3 * d.I * d.D;
+  w.out = l; l += (long long)d.D * d.I;
+  w.fc1 = l; l += (long long)d.M * d.D;
+  w.fc2 = l; l += (long long)d.D * d.M;
+  w.layer0 = o; w.layer_elems = al4(l);
+  o += w.layer_elems * d.L;
+  w.total = o;
+  return w;
+}
+
+// activation workspace in BYTES
+struct Wsb {
+  long long patches, xa, xb, pooled, layer0, layer_stride, total;
+  long long ln, qkv, ao, lse, xmid, a1, layer_bytes;   // relative to the layer base
+};
+Wsb make_wsb(const Dims& d, int save) {
+  Wsb w;
+  long long o = 0;
+  w.patches = o; o += al128((long long)d.B * d.P * d.pd * 2);
+  w.xa = o; o += al128(d.T * d.D * 4);
+  w.xb = o; o += al128(d.T * d.D * 4);
+  w.pooled = o; o += al128((long long)d.B * d.D * 4);
+  long long l = 0;
+  w.ln = l; l += al128(d.T * d.D * 2);
+  w.qkv = l; l += al128(d.T * 3 * d.I * 2);
+  w.ao = l; l += al128(d.T * d.I * 2);
+  w.lse = l; l += al128((long long)d.B * d.H * d.N * 4);
+  w.xmid = l; l += al128(d.T * d.D * 4);
+  w.a1 = l; l += al128(d.T * d.M * 2);
+  w.layer0 = o; w.layer_bytes = l;
+  w.layer_stride = save ? l : 0;
+  o += save ? l * d.L : l;
+  w.total = o;
+  return w;
+}
+
+int check_bf16_dims(const Dims& d) {
+  DGVIT_CHECK_ARG(d.dh == 64, "bf16 path: dim_head=%d unsupported (64)", d.dh);
+  DGVIT_CHECK_ARG(d.D % 8 == 0 && d.M % 8 == 0 && d.pd % 8 == 0, "bf16 path: dim, mlp_dim and patch pixels must be multiples of 8");
+  return DGVIT_OK;
+}
+
+GemmBf16Params gpb(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, int ldc, int M, int N, int K) {
+  GemmBf16Params p = {};
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+  return p;
+}
+
+}  // namespace
+
+extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = tile; }
+
+extern "C" long long dgvit_got_bf16_weight_elems(const dgvit_config* cfg) {
+  Dims d;
+  if (make_dims(cfg, 1, d) || check_bf16_dims(d)) return -1;
+  return make_wp(d).total;
+}
+
+extern "C" long long dgvit_got_bf16_workspace_bytes(const dgvit_config* cfg, int batch, int save) {
+  Dims d;
+  if (make_dims(cfg, batch, d) || check_bf16_dims(d)) return -1;
+  DGVIT_CHECK_ARG(!save, "bf16 path: save_for_backward is not supported yet");
+  return make_wsb(d, save).total;
+}
+
+extern "C" int dgvit_got_pack_weights_bf16(const dgvit_config* cfg, const float* const* params, unsigned short* wpack,
+                                           long long wpack_elems, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Dims d;
+  TRY(make_dims(cfg, 1, d));
+  TRY(check_bf16_dims(d));
+  DGVIT_CHECK_ARG(params && wpack, "dgvit_got_pack_weights_bf16: null pointer");
+  const Wp w = make_wp(d);
+  if (wpack_elems < w.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "bf16 weight arena %lld < %lld elements", wpack_elems, w.total);
+  TRY(cast_f32_bf16(params[P_PW], wpack + w.patch, (long long)d.D * d.pd, st));
+  for (int i = 0; i < d.L; ++i) {
+    const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
+    bf16_t* lw = wpack + w.layer0 + w.layer_elems * i;
+    TRY(cast_f32_bf16(lp[L_QKV], lw + w.qkv, (long long)3 * d.I * d.D, st));
+    TRY(cast_f32_bf16(lp[L_OUTW], lw + w.out, (long long)d.D * d.I, st));
+    TRY(cast_f32_bf16(lp[L_FC1W], lw + w.fc1, (long long)d.M * d.D, st));
+    TRY(cast_f32_bf16(lp[L_FC2W], lw + w.fc2, (long long)d.D * d.M, st));
+  }
+  return DGVIT_OK;
+}
+
+extern "C" int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* const* params, const unsigned short* wpack,
+                                      const float* img, const float* goal, float* feat, void* workspace, long long ws_bytes,
+                                      int batch, int save, float keep, unsigned long long seed,
+                                      const unsigned long long* seed_dev, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Dims d;
+  TRY(make_dims(cfg, batch, d));
+  TRY(check_bf16_dims(d));
+  DGVIT_CHECK_ARG(params && wpack && img && goal && feat && workspace, "dgvit_got_forward_bf16: null pointer");
+  DGVIT_CHECK_ARG(!save, "bf16 path: save_for_backward is not supported yet");
+  DGVIT_CHECK_ARG(keep > 0.f && keep <= 1.f, "dropout_keep must be in (0, 1]");
+  const Wsb w = make_wsb(d, save);
+  const Wp wp = make_wp(d);
+  if (ws_bytes < w.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "bf16 forward workspace %lld < %lld bytes", ws_bytes, w.total);
+  DGVIT_CHECK_ARG((uintptr_t)workspace % 256 == 0 && (uintptr_t)wpack % 16 == 0, "bf16 path: workspace must be 256-byte aligned");
+  for (int i = 0; i < P_L0 + DGVIT_PARAMS_PER_LAYER * d.L; ++i) DGVIT_CHECK_ARG(params[i], "parameter %d is null", i);
+  unsigned char* ws = (unsigned char*)workspace;
+  const int T = (int)d.T;
+
+  bf16_t* patches = (bf16_t*)(ws + w.patches);
+  float* x = (float*)(ws + w.xa);
+  float* xnext = (float*)(ws + w.xb);
+  TRY(patchify_bf16(img, patches, d.B, cfg->image_h, cfg->image_w, cfg->patch_h, cfg->patch_w, st));
+  {
+    GemmBf16Params p = gpb(patches, d.pd, wpack + wp.patch, d.pd, x, d.D, d.B * d.P, d.D, d.pd);
+    p.bias = params[P_PB];
+    p.res = params[P_POS]; p.ldr = d.D; p.res_mod = d.P;
+    p.c_rgrp = d.P;
+    TRY(gemm_bf16(BEPI_F32, p, st));
+  }
+  TRY(goal_row(goal, params[P_POS], x, d.B, d.N, d.D, st));
+  if (keep < 1.f) TRY(dropout_inplace(x, d.T * d.D, seed, seed_dev, keep, st));
+
+  for (int i = 0; i < d.L; ++i) {
+    const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
+    const bf16_t* lw = wpack + wp.layer0 + wp.layer_elems * i;
+    unsigned char* lb = ws + w.layer0 + w.layer_stride * i;
+    bf16_t* ln = (bf16_t*)(lb + w.ln);
+    bf16_t* qkv = (bf16_t*)(lb + w.qkv);
+    bf16_t* ao = (bf16_t*)(lb + w.ao);
+    float* xmid = (float*)(lb + w.xmid);
+    bf16_t* a1 = (bf16_t*)(lb + w.a1);
+    const bool last = g_prune_last && !d.pool_mean && i == d.L - 1;   // see dgvit_got_forward
+    const int tok = last ? d.B : T, rs = last ? d.N : 1;
+    TRY(layernorm_fwd_bf16(x, lp[L_LN1W], lp[L_LN1B], ln, nullptr, nullptr, T, d.D, 1e-5f, 1, st));
+    if (!last) {
+      GemmBf16Params p = gpb(ln, d.D, lw + wp.qkv, d.D, qkv, 3 * d.I, T, 3 * d.I, d.D);
+      TRY(gemm_bf16(BEPI_BF16, p, st));
+    } else {
+      GemmBf16Params kv = gpb(ln, d.D, lw + wp.qkv + (long long)d.I * d.D, d.D, qkv + d.I, 3 * d.I, T, 2 * d.I, d.D);
+      TRY(gemm_bf16(BEPI_BF16, kv, st));
+      GemmBf16Params q = gpb(ln, rs * d.D, lw + wp.qkv, d.D, qkv, rs * 3 * d.I, tok, d.I, d.D);
+      TRY(gemm_bf16(BEPI_BF16, q, st));
+    }
+    TRY(attention_fwd_bf16(qkv, ao, nullptr, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
+    {
+      GemmBf16Params p = gpb(ao, rs * d.I, lw + wp.out, d.I, xmid, rs * d.D, tok, d.D, d.I);
+      p.bias = lp[L_OUTB]; p.res = x; p.ldr = rs * d.D;
+      TRY(gemm_bf16(BEPI_F32, p, st));
+    }
+    TRY(layernorm_fwd_bf16(xmid, lp[L_LN2W], lp[L_LN2B], ln, nullptr, nullptr, tok, d.D, 1e-5f, rs, st));
+    {
+      GemmBf16Params p = gpb(ln, rs * d.D, lw + wp.fc1, d.D, a1, d.M, tok, d.M, d.D);
+      p.bias = lp[L_FC1B];
+      TRY(gemm_bf16(BEPI_GELU_BF16, p, st));
+    }
+    {
+      GemmBf16Params p = gpb(a1, d.M, lw + wp.fc2, d.M, xnext, rs * d.D, tok, d.D, d.M);
+      p.bias = lp[L_FC2B]; p.res = xmid; p.ldr = rs * d.D;
+      TRY(gemm_bf16(BEPI_F32, p, st));
+    }
+    std::swap(x, xnext);
+  }
+  if (d.pool_mean) {
+    float* pooled = (float*)(ws + w.pooled);
+    TRY(avgpool(x, pooled, d.B, d.N, d.D, st));
+    return rmsnorm_fwd(pooled, d.D, params[P_RMS], feat, d.B, d.D, st);
+  }
+  return rmsnorm_fwd(x, (long long)d.N * d.D, params[P_RMS], feat, d.B, d.D, st);
+}
+
+// operator-level exports of the bf16 kernels (parity tests, benches)
+extern "C" int dgvit_cast_f32_bf16(const float* src, unsigned short* dst, long long n, void* stream) {
+  return cast_f32_bf16(src, dst, n, (hipStream_t)stream);
+}
+extern "C" int dgvit_gemm_bf16(int epilogue, const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc,
+                               int M, int N, int K, const float* bias, const float* res, int ldr, unsigned short* C2, int ldc2,
+                               const unsigned short* aux, int ldaux, void* stream) {
+  DGVIT_CHECK_ARG(A && B && C, "dgvit_gemm_bf16: null pointer");
+  GemmBf16Params p = gpb(A, lda, B, ldb, C, ldc, M, N, K);
+  p.bias = bias; p.res = res; p.ldr = ldr; p.C2 = C2; p.ldc2 = ldc2; p.aux = aux; p.ldaux = ldaux;
+  DGVIT_CHECK_ARG(epilogue != BEPI_DGELU_BF16 || aux, "dgvit_gemm_bf16: epilogue 3 needs aux");
+  return gemm_bf16(epilogue, p, (hipStream_t)stream);
+}
+extern "C" int dgvit_layernorm_forward_bf16(const float* x, const float* gamma, const float* beta, unsigned short* y, float* mean,
+                                            float* rstd, int rows, int D, void* stream) {
+  return layernorm_fwd_bf16(x, gamma, beta, y, mean, rstd, rows, D, 1e-5f, 1, (hipStream_t)stream);
+}
+extern "C" int dgvit_attention_forward_bf16(const unsigned short* qkv, unsigned short* out, float* lse, int B, int N, int H, int dh,
+                                            void* stream) {
+  return attention_fwd_bf16(qkv, out, lse, B, N, H, dh, N, (hipStream_t)stream);
+}

@@ -1,0 +1,112 @@
+// HBM-bound helpers of the bf16 configuration: fp32 -> bf16 casts (weights), patch gather straight to bf16,
+// LayerNorm reading the fp32 residual stream and writing the bf16 GEMM operand, bf16 transposes (backward operands).
+#include "bf16.h"
+#include "kernels.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) cast_f32_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const fx4 v = reinterpret_cast<const fx4*>(src)[i];
+  reinterpret_cast<bf16x4*>(dst)[i] = __builtin_convertvector(v, bf16x4);
+}
+
+// 'b (h p1) (w p2) -> b (h w) (p1 p2)' (GoalFormer.py:138) with the cast to bf16 fused
+__global__ void __launch_bounds__(256) patchify_bf16_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B, int Hi,
+                                                            int Wi, int ph, int pw) {
+  const int gw = Wi / pw, gh = Hi / ph, pd = ph * pw;
+  const long long total = (long long)B * gh * gw * pd;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int e = (int)(idx % pd);
+  const long long bp = idx / pd;
+  const int p = (int)(bp % (gh * gw));
+  const long long b = bp / (gh * gw);
+  const int p1 = e / pw, p2 = e % pw, hy = p / gw, wx = p % gw;
+  const __bf16 v = (__bf16)img[(b * Hi + hy * ph + p1) * Wi + wx * pw + p2];
+  out[idx] = __builtin_bit_cast(bf16_t, v);
+}
+
+// nn.LayerNorm(D), eps 1e-5 (GoalFormer.py:34,37): fp32 row in, bf16 row out; one wave per row, row kept in registers
+template <int NCH>
+__global__ void __launch_bounds__(256) layernorm_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd, int T, int D,
+                                                                 float eps, int rs) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= T) return;
+  const float* xr = x + (long long)row * rs * D;
+  fx4 v[NCH];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 4 + i * 256;
+    v[i] = fx4{0.f, 0.f, 0.f, 0.f};
+    if (c < D) v[i] = *reinterpret_cast<const fx4*>(xr + c);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < D) {
+      const fx4 d = v[i] - mu;
+      q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+  const float rsd = rsqrtf(wave_sum(q) / (float)D + eps);
+  bf16_t* yr = y + (long long)row * rs * D;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane * 4 + i * 256;
+    if (c < D) {
+      const fx4 g = *reinterpret_cast<const fx4*>(gamma + c);
+      const fx4 b = *reinterpret_cast<const fx4*>(beta + c);
+      const fx4 o = (v[i] - mu) * rsd * g + b;
+      *reinterpret_cast<bf16x4*>(yr + c) = __builtin_convertvector(o, bf16x4);
+    }
+  }
+  if (mean && lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rsd;
+  }
+}
+
+}  // namespace
+
+int cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t st) {
+  DGVIT_CHECK_ARG(src && dst && n > 0 && n % 4 == 0, "cast_f32_bf16: n must be a positive multiple of 4");
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, src, dst, n4);
+  DGVIT_CHECK_LAUNCH("cast_f32_bf16");
+  return DGVIT_OK;
+}
+
+int patchify_bf16(const float* img, bf16_t* out, int B, int Hi, int Wi, int ph, int pw, hipStream_t st) {
+  DGVIT_CHECK_ARG(img && out && B > 0, "patchify_bf16: bad arguments");
+  DGVIT_CHECK_ARG(ph > 0 && pw > 0 && Hi % ph == 0 && Wi % pw == 0, "Image dimensions must be divisible by the patch size.");
+  const long long total = (long long)B * Hi * Wi;
+  hipLaunchKernelGGL(patchify_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, out, B, Hi, Wi, ph, pw);
+  DGVIT_CHECK_LAUNCH("patchify_bf16");
+  return DGVIT_OK;
+}
+
+int layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int T, int D,
+                       float eps, int rs, hipStream_t st) {
+  DGVIT_CHECK_ARG(x && gamma && beta && y && T > 0, "layernorm_bf16: bad arguments");
+  DGVIT_CHECK_ARG(D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bf16: D=%d must be a multiple of 4 and <= 1024", D);
+  const int slot = profile_begin(PROF_OTHER, 0.0, st);
+  const dim3 grid((unsigned)((T + 3) / 4)), blk(256);
+  if (D <= 256)
+    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<1>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, T, D, eps, rs);
+  else if (D <= 512)
+    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<2>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, T, D, eps, rs);
+  else
+    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<4>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, T, D, eps, rs);
+  profile_end(slot, st);
+  DGVIT_CHECK_LAUNCH("layernorm_fwd_bf16");
+  return DGVIT_OK;
+}

@@ -297,3 +297,116 @@ def op_dropout_(x, seed, keep):
     lib = _lib.load()
     _lib.check(lib.dgvit_dropout(_ptr(x), x.numel(), int(seed), float(keep), _stream()), "dgvit_dropout")
     return x
+
+
+# ------------------------------------------------------------------------------------------------ bf16 configuration
+def _dev_bf16(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.bfloat16:
+        raise DgvitError(f"{name}: expected a bf16 tensor on a ROCm device")
+    return t.contiguous()
+
+
+def cast_bf16(x):
+    """fp32 -> bf16 (round to nearest even) on the HIP path; numel must be a multiple of 4."""
+    lib = _lib.load()
+    x = _dev(x, "x")
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dgvit_cast_f32_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), "dgvit_cast_f32_bf16")
+    return y
+
+
+def op_gemm_bf16(epilogue, a, b, bias=None, res=None, aux=None, want_c2=False):
+    """C = A B^T (+ epilogue) with A (M,K), B (N,K) bf16; see dgvit_gemm_bf16 in dgvit_hip.h."""
+    lib = _lib.load()
+    a, b = _dev_bf16(a, "a"), _dev_bf16(b, "b")
+    M, K = a.shape
+    N = b.shape[0]
+    out_dtype = torch.float32 if epilogue in (2, 4) else torch.bfloat16
+    c = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    c2 = torch.empty(M, N, dtype=torch.bfloat16, device=a.device) if want_c2 else None
+    bias = None if bias is None else _dev(bias, "bias")
+    res = None if res is None else _dev(res, "res")
+    aux = None if aux is None else _dev_bf16(aux, "aux")
+    with torch.cuda.device(a.device):
+        rc = lib.dgvit_gemm_bf16(int(epilogue), _ptr(a), K, _ptr(b), K, _ptr(c), N, M, N, K, _ptr(bias), _ptr(res), N, _ptr(c2), N,
+                                 _ptr(aux), N, _stream())
+    _lib.check(rc, "dgvit_gemm_bf16")
+    return (c, c2) if want_c2 else c
+
+
+def op_layernorm_bf16(x, gamma, beta):
+    lib = _lib.load()
+    x, gamma, beta = _dev(x, "x"), _dev(gamma, "gamma"), _dev(beta, "beta")
+    rows, D = x.shape
+    y = torch.empty(rows, D, dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.dgvit_layernorm_forward_bf16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), rows, D, _stream())
+    _lib.check(rc, "dgvit_layernorm_forward_bf16")
+    return y, mean, rstd
+
+
+def op_attention_bf16(qkv, heads, dim_head=64, want_lse=False):
+    lib = _lib.load()
+    qkv = _dev_bf16(qkv, "qkv")
+    B, N, W = qkv.shape
+    if W != 3 * heads * dim_head:
+        raise DgvitError(f"qkv last dim {W} != 3*{heads}*{dim_head}")
+    out = torch.empty(B, N, heads * dim_head, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(B, heads, N, dtype=torch.float32, device=qkv.device) if want_lse else None
+    with torch.cuda.device(qkv.device):
+        rc = lib.dgvit_attention_forward_bf16(_ptr(qkv), _ptr(out), _ptr(lse), B, N, heads, dim_head, _stream())
+    _lib.check(rc, "dgvit_attention_forward_bf16")
+    return (out, lse) if want_lse else out
+
+
+class Bf16Weights:
+    """bf16 copies of an encoder's GEMM weights in one arena (dgvit_got_pack_weights_bf16), re-packed only when a master
+    parameter has changed (tensor version counters)."""
+
+    def __init__(self):
+        self.arena = None
+        self.key = None
+
+    def get(self, cfg, params):
+        lib = _lib.load()
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self.arena is None or key != self.key or self.arena.device != params[0].device:
+            n = lib.dgvit_got_bf16_weight_elems(ctypes.byref(cfg))
+            if n < 0:
+                _lib.check(-1, "dgvit_got_bf16_weight_elems")
+            if self.arena is None or self.arena.numel() != n or self.arena.device != params[0].device:
+                self.arena = torch.empty(n, dtype=torch.bfloat16, device=params[0].device)
+            with torch.cuda.device(params[0].device):
+                rc = lib.dgvit_got_pack_weights_bf16(ctypes.byref(cfg), _table(params), _ptr(self.arena), n, _stream())
+            _lib.check(rc, "dgvit_got_pack_weights_bf16")
+            self.key = key
+        return self.arena
+
+
+def got_encoder_bf16(img, goal, cfg_tuple, params, weights: Bf16Weights, dropout_keep=1.0, dropout_seed=0):
+    """GoT.forward in the bf16 configuration (inference: no autograd graph is recorded)."""
+    lib = _lib.load()
+    cfg = dgvit_config(*cfg_tuple)
+    img, goal = _dev(img, "img"), _dev(goal, "goal")
+    params = [_dev(p.detach(), f"param[{i}]") for i, p in enumerate(params)]
+    if img.dim() != 3 or img.shape[1] != cfg.image_h or img.shape[2] != cfg.image_w:
+        raise DgvitError(f"img must be (B, {cfg.image_h}, {cfg.image_w}), got {tuple(img.shape)}")
+    B = img.shape[0]
+    if goal.shape != (B, cfg.dim):
+        raise DgvitError(f"goal must be ({B}, {cfg.dim}), got {tuple(goal.shape)}")
+    wpack = weights.get(cfg, params)
+    nws = lib.dgvit_got_bf16_workspace_bytes(ctypes.byref(cfg), B, 0)
+    if nws < 0:
+        _lib.check(-1, "dgvit_got_bf16_workspace_bytes")
+    ws = torch.empty(nws, dtype=torch.uint8, device=img.device)
+    feat = torch.empty(B, cfg.dim, dtype=torch.float32, device=img.device)
+    seed_dev = dropout_seed if isinstance(dropout_seed, torch.Tensor) else None
+    seed_val = 0 if seed_dev is not None else int(dropout_seed)
+    with torch.cuda.device(img.device):
+        rc = lib.dgvit_got_forward_bf16(ctypes.byref(cfg), _table(params), _ptr(wpack), _ptr(img), _ptr(goal), _ptr(feat), _ptr(ws),
+                                        nws, B, 0, float(dropout_keep), seed_val, _ptr(seed_dev), _stream())
+    _lib.check(rc, "dgvit_got_forward_bf16")
+    return feat

@@ -107,6 +107,16 @@ class GoT(nn.Module):
         self.mlp_head = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, num_classes))  # unused, kept for checkpoints
         self._cfg = (image_height, image_width, patch_height, patch_width, dim, depth, heads, dim_head, mlp_dim,
                      1 if pool == 'mean' else 0)
+        self.compute_dtype = torch.float32
+        self._bf16_weights = F_.Bf16Weights()
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (default: exact fp32 MFMA path) or torch.bfloat16 (BASELINE config 5: bf16 storage for the GEMM
+        operands, fp32 residual stream / statistics / accumulation; parameters stay fp32 masters)."""
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f"compute dtype {dtype} unsupported (torch.float32 or torch.bfloat16)")
+        self.compute_dtype = dtype
+        return self
 
     def param_table(self):
         """Parameters in the order of include/dgvit_hip.h's table."""
@@ -126,4 +136,9 @@ class GoT(nn.Module):
                 seed = torch.empty(1, dtype=torch.int64, device=img.device).random_()
             else:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())   # CPU generator: follows torch.manual_seed, no device sync
-        return F_.got_encoder(img, goal, self._cfg, self.param_table(), keep, seed)
+        params = self.param_table()
+        if self.compute_dtype == torch.bfloat16:
+            if torch.is_grad_enabled() and (goal.requires_grad or any(p.requires_grad for p in params)):
+                raise NotImplementedError("the bf16 configuration has no backward yet: call it under torch.no_grad()")
+            return F_.got_encoder_bf16(img, goal, self._cfg, params, self._bf16_weights, keep, seed)
+        return F_.got_encoder(img, goal, self._cfg, params, keep, seed)

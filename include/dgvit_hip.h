@@ -21,7 +21,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define DGVIT_ABI_VERSION 2
+#define DGVIT_ABI_VERSION 3
 
 /* error codes */
 #define DGVIT_OK 0
@@ -196,6 +196,42 @@ int dgvit_gather_rows(const float* src, const long long* idx, float* out, long l
 int dgvit_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, long long step, const long long* step_dev, void* stream);
 int dgvit_soft_update(float* target, const float* source, long long n, float tau, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * bf16 configuration (BASELINE.json config 5: 224x224 depth frames, 12-layer ViT-Base variant with goal token, bf16).
+ * Same GoT.forward (GoalFormer.py:156-171) with bf16 STORAGE for every GEMM operand (LayerNorm outputs, qkv, attention
+ * output, MLP hidden, the four weight matrices of each block and the patch weight) and fp32 everywhere else (residual
+ * stream, LayerNorm statistics, biases, softmax, accumulation on v_mfma_f32_32x32x16_bf16, RMSNorm, output).
+ * bf16 values are raw 16-bit patterns (unsigned short).  Needs dim_head 64 and dim, mlp_dim, patch pixels % 8 == 0.
+ *   wpack: bf16 copies of the GEMM weights in one arena of dgvit_got_bf16_weight_elems elements
+ *          [patch weight | per layer: to_qkv, to_out, fc1, fc2], refreshed with dgvit_got_pack_weights_bf16 whenever the
+ *          fp32 master parameters change; `params` is the fp32 table of dgvit_got_forward (biases, norms, pos_embedding).
+ *   workspace: dgvit_got_bf16_workspace_bytes BYTES, 256-byte aligned.
+ * -------------------------------------------------------------------------------------------- */
+long long dgvit_got_bf16_weight_elems(const dgvit_config* cfg);
+int dgvit_got_pack_weights_bf16(const dgvit_config* cfg, const float* const* params, unsigned short* wpack,
+                                long long wpack_elems, void* stream);
+long long dgvit_got_bf16_workspace_bytes(const dgvit_config* cfg, int batch, int save_for_backward);
+int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* const* params, const unsigned short* wpack, const float* img,
+                           const float* goal, float* feat, void* workspace, long long workspace_bytes, int batch,
+                           int save_for_backward, float dropout_keep, unsigned long long dropout_seed,
+                           const unsigned long long* dropout_seed_dev, void* stream);
+/* operator-level entry points of the bf16 kernels (parity tests, benches) */
+int dgvit_cast_f32_bf16(const float* src, unsigned short* dst, long long n, void* stream);
+/* C = A B^T (+ epilogue), A (M,K) / B (N,K) bf16 with k contiguous, K, lda, ldb % 8 == 0, N, ldc % 4 == 0.
+ * epilogue 0: C bf16 = acc + bias;  1: C bf16 = gelu(acc + bias), C2 bf16 = acc + bias (optional);
+ *          2: C fp32 = acc + bias + res (fp32);  3: C bf16 = acc * gelu'(aux bf16);  4: C fp32 = acc. */
+int dgvit_gemm_bf16(int epilogue, const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, int M,
+                    int N, int K, const float* bias, const float* res, int ldr, unsigned short* C2, int ldc2,
+                    const unsigned short* aux, int ldaux, void* stream);
+/* test/bench knob: force the bf16 GEMM workgroup tile (0 = automatic; 256256, 256128, 128128) */
+void dgvit_set_gemm_bf16_tile(int tile);
+/* LayerNorm with fp32 input and bf16 output (mean / rstd may be NULL) */
+int dgvit_layernorm_forward_bf16(const float* x, const float* gamma, const float* beta, unsigned short* y, float* mean,
+                                 float* rstd, int rows, int D, void* stream);
+/* attention core on bf16 qkv (B, N, 3*H*64) -> bf16 out (B, N, H*64); lse fp32 (B, H, N) or NULL */
+int dgvit_attention_forward_bf16(const unsigned short* qkv, unsigned short* out, float* lse, int B, int N, int H, int dh,
+                                 void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Optional live kernel timing (HIP events on the launch stream around every kernel launch).

@@ -311,6 +311,47 @@ def got_forward(p: Dict[str, Tensor], img: Tensor, goal: Tensor, cfg: GoTConfig,
 
 
 # --------------------------------------------------------------------------
+# bf16 configuration (BASELINE config 5): the same GoT.forward with the STORAGE roundings of the HIP bf16 path
+# modelled (every GEMM operand -- patches, LayerNorm outputs, q/k/v, attention probabilities and output, GELU
+# output, the GEMM weights -- rounded to bf16; residual stream, statistics, biases, softmax and all sums in the
+# working dtype).  Pinned two ways in tests/: against the fp32 restatement above (distance = the precision cost of
+# bf16 storage) and against the reference run under torch.autocast(bfloat16) (tests/golden/make_golden_bf16.py).
+# --------------------------------------------------------------------------
+def rb(x: Tensor) -> Tensor:
+    """round to bf16 (nearest even) and back"""
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+def got_forward_bf16(p: Dict[str, Tensor], img: Tensor, goal: Tensor, cfg: GoTConfig,
+                     drop_mask: Optional[Tensor] = None, prefix: str = "trans.", pool: str = "cls",
+                     drop_p: float = 0.1) -> Tensor:
+    x = linear(rb(patchify(img, cfg)), rb(p[prefix + "to_patch_embedding.1.weight"]),
+               p[prefix + "to_patch_embedding.1.bias"])                       # GoalFormer.py:157
+    x = torch.cat([goal.unsqueeze(1), x], dim=1)                              # :160-161
+    x = x + p[prefix + "pos_embedding"][:, :x.shape[1]]                       # :162
+    if drop_mask is not None:                                                 # :163
+        x = x * drop_mask / (1.0 - drop_p)
+    B, N, _ = x.shape
+    H, dh = cfg.heads, cfg.dim_head
+    I = H * dh
+    for i in range(cfg.depth):                                                # :165, 101-105
+        lp = f"{prefix}transformer.layers.{i}."
+        h = rb(layer_norm(x, p[lp + "0.norm.weight"], p[lp + "0.norm.bias"]))
+        qkv = rb(linear(h, rb(p[lp + "0.fn.to_qkv.weight"])))                 # :72
+        q, k, v = (qkv[..., j * I:(j + 1) * I].reshape(B, N, H, dh).permute(0, 2, 1, 3) for j in range(3))
+        dots = (q @ k.transpose(-1, -2)) * (dh ** -0.5)                       # :75
+        e = torch.exp(dots - dots.amax(-1, keepdim=True))
+        out = (rb(e) @ v) / e.sum(-1, keepdim=True)                           # :77-80 (probabilities stored bf16, sum fp32)
+        out = rb(out.permute(0, 2, 1, 3).reshape(B, N, I))                    # :81
+        x = linear(out, rb(p[lp + "0.fn.to_out.0.weight"]), p[lp + "0.fn.to_out.0.bias"]) + x
+        h = rb(layer_norm(x, p[lp + "1.norm.weight"], p[lp + "1.norm.bias"]))
+        a = rb(gelu_exact(linear(h, rb(p[lp + "1.fn.net.0.weight"]), p[lp + "1.fn.net.0.bias"])))
+        x = linear(a, rb(p[lp + "1.fn.net.3.weight"]), p[lp + "1.fn.net.3.bias"]) + x
+    pooled = x.mean(dim=1) if pool == "mean" else x[:, 0]                     # :167
+    return rms_norm(pooled, p[prefix + "layer_norm.g"])                       # :170
+
+
+# --------------------------------------------------------------------------
 # heads
 # --------------------------------------------------------------------------
 def policy_forward(p, istate, pstate, cfg: GoTConfig, drop_mask=None):

@@ -1,0 +1,206 @@
+"""GPU: the bf16 configuration (BASELINE config 5) -- operator-level parity of the bf16 kernels against fp64 CPU
+arithmetic on the SAME bf16-rounded inputs, and encoder-level parity against the oracle and the reference's own
+bf16 (autocast) and fp32 outputs.
+
+Tolerances (written per test): a bf16 result carries one output rounding (relative 2^-9 = 0.2 %); fp32 outputs of
+the bf16 GEMM only carry fp32 accumulation error.  Encoder features are RMS-normalised (unit RMS), so absolute
+tolerances on them are relative ones."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import O, load_fixture, fixture_cfg  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def F():
+    import dgvit_amd
+    dgvit_amd.load_library()
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return dgvit_amd.functional
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
+
+
+def rb(t):
+    """bf16-round a float64 tensor (what the device operand holds)"""
+    return t.float().to(torch.bfloat16).double()
+
+
+def dbf(t):
+    return t.float().to(torch.bfloat16).cuda()
+
+
+def close(got, ref, atol, rtol=0.0, msg=""):
+    np.testing.assert_allclose(got.detach().double().cpu().numpy(), ref.double().numpy(), rtol=rtol, atol=atol, err_msg=msg)
+
+
+def test_cast_matches_torch_rounding(F):
+    x = rnd(4096 * 4, seed=1).float()
+    x[:8] = torch.tensor([0.0, -0.0, 1.0, 1.00390625, 1.001953125, 3.4e38, 1e-40, -2.5])   # ties, large, subnormal
+    y = F.cast_bf16(x.cuda())
+    assert torch.equal(y.cpu().view(torch.int16), x.to(torch.bfloat16).view(torch.int16))
+
+
+GEMM_SHAPES = [(256, 256, 64), (512, 768, 768), (200, 136, 104), (50, 64, 256), (1, 4, 128), (37, 132, 264), (300, 8, 48),
+               (197 * 3, 2304, 768), (1000, 768, 3072)]
+
+
+@pytest.mark.parametrize("tile", [0, 128128, 256128, 256256])
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_bf16_f32_out_bias_residual(F, M, N, K, tile):
+    """fp32 output = exact products of bf16 operands summed in fp32: error is accumulation only"""
+    import dgvit_amd
+    lib = dgvit_amd.load_library()
+    a, b, bias, res = rb(rnd(M, K, seed=1)), rb(rnd(N, K, seed=2)), rnd(N, seed=3).float().double(), rnd(M, N, seed=4).float().double()
+    lib.dgvit_set_gemm_bf16_tile(tile)
+    try:
+        y = F.op_gemm_bf16(2, dbf(a), dbf(b), bias=bias.float().cuda(), res=res.float().cuda())
+    finally:
+        lib.dgvit_set_gemm_bf16_tile(0)
+    close(y, a @ b.T + bias + res, atol=2e-5 * K ** 0.5 + 1e-5 * K ** 0.5 * 8, msg=f"{M}x{N}x{K} tile {tile}")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (200, 136, 104), (591, 2304, 768), (37, 132, 264)])
+def test_gemm_bf16_bf16_out_and_gelu(F, M, N, K):
+    a, b, bias = rb(rnd(M, K, seed=5)), rb(rnd(N, K, seed=6, scale=K ** -0.5)), rnd(N, seed=7).float().double()
+    h = a @ b.T + bias
+    y = F.op_gemm_bf16(0, dbf(a), dbf(b), bias=bias.float().cuda())
+    close(y, h, atol=1e-5, rtol=2 ** -8, msg="bf16 out")                # one bf16 rounding of the output
+    g, pre = F.op_gemm_bf16(1, dbf(a), dbf(b), bias=bias.float().cuda(), want_c2=True)
+    close(pre, h, atol=1e-5, rtol=2 ** -8, msg="pre-activation")
+    close(g, O.gelu_exact(h), atol=2e-5, rtol=2 ** -8, msg="gelu")
+    # gelu' epilogue: C = acc * gelu'(aux)
+    aux = rb(rnd(M, N, seed=8))
+    x = aux
+    dg = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-x * x / 2) / math.sqrt(2 * math.pi)
+    y3 = F.op_gemm_bf16(3, dbf(a), dbf(b), aux=dbf(aux))
+    close(y3, (a @ b.T) * dg, atol=3e-5, rtol=2 ** -8, msg="dgelu")
+    y4 = F.op_gemm_bf16(4, dbf(a), dbf(b))
+    close(y4, a @ b.T, atol=2e-5 * K ** 0.5, msg="plain fp32")
+
+
+def test_gemm_bf16_identity_asymmetric(F):
+    """A = I with an asymmetric integer B catches any row/column or k-order mix-up exactly"""
+    n = 256
+    a = torch.eye(n, dtype=torch.float64)
+    b = (torch.arange(n, dtype=torch.float64)[:, None] * 3 + torch.arange(n, dtype=torch.float64)[None, :] % 7) % 251
+    y = F.op_gemm_bf16(4, dbf(a), dbf(b))
+    assert torch.equal(y.cpu().double(), b.T.contiguous())
+
+
+@pytest.mark.parametrize("rows,D", [(8, 64), (1001, 256), (197 * 2, 768), (5, 1024), (33, 520)])
+def test_layernorm_bf16(F, rows, D):
+    x, g, b = rnd(rows, D, seed=1, scale=2.0).float().double() + 0.5, rnd(D, seed=2).float().double(), rnd(D, seed=3).float().double()
+    y, mean, rstd = F.op_layernorm_bf16(x.float().cuda(), g.float().cuda(), b.float().cuda())
+    ref = O.layer_norm(x, g, b)
+    close(y, ref, atol=1e-5, rtol=2 ** -8)
+    close(mean, x.mean(-1), atol=1e-5)
+    close(rstd, torch.rsqrt(x.var(-1, unbiased=False) + 1e-5), atol=0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 50, 8), (2, 1, 2), (1, 32, 1), (2, 33, 3), (1, 224, 2), (4, 65, 4)])
+def test_attention_bf16(F, B, N, H):
+    dh = 64
+    qkv = rb(rnd(B, N, 3 * H * dh, seed=N))
+    out, lse = F.op_attention_bf16(dbf(qkv), H, dh, want_lse=True)
+    I = H * dh
+    q, k, v = (qkv[..., j * I:(j + 1) * I].reshape(B, N, H, dh).permute(0, 2, 1, 3) for j in range(3))
+    dots = (q @ k.transpose(-1, -2)) * dh ** -0.5
+    ref = (torch.softmax(dots, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, I)
+    # probabilities are rounded to bf16 before P.V (relative 2^-9 each, averaging out) and the output once more
+    close(out, ref, atol=6e-3, rtol=2 ** -7, msg=f"attention B{B} N{N} H{H}")
+    close(lse, torch.logsumexp(dots, -1) / math.log(2.0), atol=2e-4, msg="lse (base 2)")
+
+
+def test_attention_bf16_large_logits(F):
+    """rows whose maximum moves from tile to tile exercise the online-softmax rescale"""
+    B, N, H, dh = 1, 197, 2, 64
+    qkv = rnd(B, N, 3 * H * dh, seed=3)
+    qkv[..., :H * dh] *= 4.0
+    qkv[0, 150:, H * dh:2 * H * dh] *= 6.0     # late keys dominate: the running max jumps in the last tiles
+    qkv = rb(qkv)
+    out = F.op_attention_bf16(dbf(qkv), H, dh)
+    I = H * dh
+    q, k, v = (qkv[..., j * I:(j + 1) * I].reshape(B, N, H, dh).permute(0, 2, 1, 3) for j in range(3))
+    ref = (torch.softmax((q @ k.transpose(-1, -2)) * dh ** -0.5, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, I)
+    close(out, ref, atol=1.5e-2, rtol=2 ** -7)
+
+
+# ---------------------------------------------------------------------------------------------- encoder
+def _run_encoder(cfg, params, img, goal, prune=True):
+    import dgvit_amd
+    lib = dgvit_amd.load_library()
+    m = dgvit_amd.GoT(image_size=cfg.image, patch_size=cfg.patch, num_classes=2, dim=cfg.dim, depth=cfg.depth, heads=cfg.heads,
+                      mlp_dim=cfg.mlp_dim, dim_head=cfg.dim_head, channels=1)
+    m.load_state_dict(params, strict=True)
+    m = m.cuda().eval().set_compute_dtype(torch.bfloat16)
+    lib.dgvit_set_prune_last_layer(1 if prune else 0)
+    try:
+        with torch.no_grad():
+            return m(img.cuda(), goal.cuda()).cpu()
+    finally:
+        lib.dgvit_set_prune_last_layer(1)
+
+
+@pytest.mark.parametrize("name", ["got_c5_l2_bf16", "got_c5_l12_bf16", "got_84p12_bf16"])
+def test_encoder_bf16_vs_reference_and_oracle(name):
+    fx = load_fixture(name)
+    cfg = fixture_cfg(fx)
+    batch, seed = int(fx["meta/batch"]), int(fx["meta/seed"])
+    params = O.make_params(O.got_param_spec(cfg, prefix=""), seed)
+    img, _, _, _ = O.make_inputs(cfg, batch, seed)
+    goal = torch.from_numpy(np.random.RandomState(seed + 7).standard_normal((batch, cfg.dim))).float()
+    feat = _run_encoder(cfg, params, img, goal)
+    dense = _run_encoder(cfg, params, img, goal, prune=False)
+    emu = O.got_forward_bf16(params, img, goal, cfg, prefix="")
+    ref32 = torch.from_numpy(fx["feat_fp32"])
+    refbf = torch.from_numpy(fx["feat_autocast_bf16"])
+    d_emu, d32, dbf_ = (feat - emu).abs(), (feat - ref32).abs(), (feat - refbf).abs()
+    print(f"{name}: vs emulation max {d_emu.max():.4f} mean {d_emu.mean():.5f} | vs ref fp32 max {d32.max():.4f} mean {d32.mean():.5f}"
+          f" | vs ref autocast max {dbf_.max():.4f} | ref autocast vs ref fp32 max {(refbf - ref32).abs().max():.4f}")
+    assert torch.isfinite(feat).all()
+    # same storage roundings modelled on the CPU: differences come from accumulation order flipping bf16 roundings
+    assert d_emu.max() < 2e-2 and d_emu.mean() < 3e-3
+    # precision cost of bf16 storage against the reference's fp32 output: no worse than 2x the reference's own autocast run
+    assert d32.max() < max(3e-2, 2 * float((refbf - ref32).abs().max()))
+    assert d32.mean() < 6e-3
+    # token-0-only schedule of the last block = dense schedule (same kernels on a row subset)
+    assert (feat - dense).abs().max() < 2e-2
+
+
+def test_encoder_bf16_needs_no_grad_and_gpu():
+    import dgvit_amd
+    m = dgvit_amd.GoT(image_size=(32, 32), patch_size=(8, 8), num_classes=2, dim=64, depth=1, heads=1, mlp_dim=64, channels=1)
+    m = m.cuda().set_compute_dtype(torch.bfloat16)
+    with pytest.raises(NotImplementedError):
+        m(torch.rand(2, 32, 32).cuda(), torch.rand(2, 64).cuda())
+    with pytest.raises(ValueError):
+        m.set_compute_dtype(torch.float16)
+
+
+def test_encoder_bf16_full_size_properties():
+    """config 5 at full depth and a real batch: frames are independent and features have unit RMS"""
+    import dgvit_amd
+    cfg = O.GoTConfig(image=(224, 224), patch=(16, 16), dim=768, depth=12, heads=12, dim_head=64, mlp_dim=3072)
+    params = O.make_params(O.got_param_spec(cfg, prefix=""), 5)
+    m = dgvit_amd.GoT(image_size=cfg.image, patch_size=cfg.patch, num_classes=2, dim=cfg.dim, depth=cfg.depth, heads=cfg.heads,
+                      mlp_dim=cfg.mlp_dim, channels=1)
+    m.load_state_dict(params, strict=True)
+    m = m.cuda().eval().set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(0)
+    img, goal = torch.rand(64, 224, 224, generator=g).cuda(), torch.randn(64, 768, generator=g).cuda()
+    with torch.no_grad():
+        full = m(img, goal)
+        part = m(img[40:48], goal[40:48])
+    assert torch.isfinite(full).all()
+    torch.testing.assert_close(full.pow(2).mean(-1).sqrt(), torch.ones(64, device="cuda"), atol=1e-4, rtol=0)
+    # a frame's features do not depend on which batch it is in (bit-exact: same kernels, same per-row arithmetic)
+    assert torch.equal(full[40:48], part)

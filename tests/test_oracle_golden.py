@@ -158,3 +158,23 @@ def test_got_meanpool_case():
     for k, v in p.items():
         if f"gfull/{k}" in fx:
             np.testing.assert_allclose(v.grad.numpy(), fx[f"gfull/{k}"], rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+# ---------------------------------------------------------------- bf16 configuration (BASELINE config 5)
+@pytest.mark.parametrize("name", ["got_c5_l2_bf16", "got_c5_l12_bf16", "got_84p12_bf16"])
+def test_oracle_bf16_model_vs_reference(name):
+    """The oracle's bf16-storage model sits as close to the reference's fp32 output as the reference's own autocast(bf16)
+    run does, and within the same distance of that autocast run (fixtures: tests/golden/make_golden_bf16.py)."""
+    fx = load_fixture(name)
+    cfg = fixture_cfg(fx)
+    batch, seed = int(fx["meta/batch"]), int(fx["meta/seed"])
+    params = O.make_params(O.got_param_spec(cfg, prefix=""), seed)
+    img, _, _, _ = O.make_inputs(cfg, batch, seed)
+    goal = torch.from_numpy(np.random.RandomState(seed + 7).standard_normal((batch, cfg.dim))).float()
+    ref32, refbf = torch.from_numpy(fx["feat_fp32"]), torch.from_numpy(fx["feat_autocast_bf16"])
+    np.testing.assert_allclose(O.got_forward(params, img, goal, cfg, prefix="").numpy(), ref32.numpy(), atol=5e-6)
+    emu = O.got_forward_bf16(params, img, goal, cfg, prefix="")
+    ref_gap = float((refbf - ref32).abs().max())
+    assert float((emu - ref32).abs().max()) < 1.5 * ref_gap + 2e-3
+    assert float((emu - refbf).abs().max()) < 1.5 * ref_gap + 2e-3
+    assert float((emu - ref32).abs().mean()) < 5e-3
