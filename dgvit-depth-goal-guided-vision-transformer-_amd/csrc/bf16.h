@@ -12,10 +12,11 @@ typedef float fx4 __attribute__((ext_vector_type(4)));
 // brought into this shape by transposed bf16 copies of their operands), fp32 accumulate on v_mfma_f32_32x32x16_bf16.
 enum GemmBf16Epilogue {
   BEPI_BF16 = 0,       // C (bf16) = acc + bias
-  BEPI_GELU_BF16 = 1,  // C (bf16) = gelu_erf(acc + bias);  C2 (bf16, optional) = acc + bias (pre-activation, training)
+  BEPI_GELU_BF16 = 1,  // C (bf16) = gelu_erf(acc + bias)
   BEPI_F32 = 2,        // C (fp32) = acc + bias + res       (residual stream stays fp32)
   BEPI_DGELU_BF16 = 3, // C (bf16) = acc * gelu'(aux)       aux (bf16) = saved pre-activation
-  BEPI_F32_PLAIN = 4   // C (fp32) = acc                    (weight gradients)
+  BEPI_F32_PLAIN = 4,  // C (fp32) = acc                    (weight gradients)
+  BEPI_GELU2_BF16 = 5  // C (bf16) = gelu_erf(acc + bias);  C2 (bf16) = acc + bias (pre-activation kept for training)
 };
 
 struct GemmBf16Params {
@@ -27,12 +28,13 @@ struct GemmBf16Params {
   const float* res; int ldr;    // fp32 residual or null
   int res_mod;                  // > 0: residual row = (m % res_mod) + 1 (positional embedding)
   int c_rgrp;                   // > 0: physical C row = m + m / c_rgrp + 1 (patch rows -> token rows)
-  bf16_t* C2; int ldc2;         // BEPI_GELU_BF16: pre-activation copy (may be null)
+  bf16_t* C2; int ldc2;         // BEPI_GELU2_BF16: pre-activation copy
   const bf16_t* aux; int ldaux; // BEPI_DGELU_BF16
 };
 
 int gemm_bf16(int epi, const GemmBf16Params& p, hipStream_t st);
 extern int g_gemm_bf16_tile_hint;
+extern long long* g_gemm_bf16_stamps;
 
 int cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t st);
 int patchify_bf16(const float* img, bf16_t* patches, int B, int ih, int iw, int ph, int pw, hipStream_t st);

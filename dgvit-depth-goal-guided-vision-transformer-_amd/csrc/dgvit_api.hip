@@ -743,6 +743,7 @@ GemmBf16Params gpb(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, 
 }  // namespace
 
 extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = tile; }
+extern "C" void dgvit_set_gemm_bf16_stamps(long long* stamps) { g_gemm_bf16_stamps = stamps; }
 
 extern "C" long long dgvit_got_bf16_weight_elems(const dgvit_config* cfg) {
   Dims d;

@@ -2,24 +2,31 @@
 // v_mfma_f32_32x32x16_bf16; fused bias / residual / erf-GELU epilogues).  The Linear layers of Attention and
 // FeedForward (GoalFormer.py:42-50,64,66-69) in the bf16 configuration (BASELINE config 5).
 //
-// Structure (one workgroup per BM x BN output tile, BK = 64):
+// Common to both kernels below (one workgroup per BM x BN output tile):
 //  * Staging is LDS-DMA: `buffer_load_dwordx4 ... lds` writes 16 bytes per lane straight into LDS (no VGPRs, no
-//    ds_write).  One wave instruction fills 8 tile rows x 128 bytes.  The LDS image is row-major with 128-byte rows
-//    whose eight 16-byte chunks are XOR-swizzled by ((row >> 1) & 7): an LDS-DMA writes lane-linearly, so the swizzle
-//    is applied to the per-lane SOURCE address, and again by the fragment reads.  With it every ds_read_b128 lane
-//    group {0-3,12-15,20-27} / {4-11,16-19,28-31} touches 16 distinct 16-byte bank slots (conflict-free).
+//    ds_write).  An LDS-DMA writes lane-linearly, so the bank swizzle of the LDS image is applied to the per-lane
+//    SOURCE address and again by the fragment reads; every ds_read_b128 lane group {0-3,12-15,20-27} /
+//    {4-11,16-19,28-31} then touches 16 distinct 16-byte bank slots (conflict-free).
 //  * Rows beyond M / N and the k tail are zero-filled by the buffer range check (offset >= num_records reads 0),
-//    so the main loop is branch-free.
-//  * Two LDS buffers: the DMA of k-tile t+1 is issued before the MFMAs of tile t and waited for after them
-//    (one barrier per k-tile).
+//    so the main loops are branch-free.
 //  * Each wave owns a (BM/WM) x (BN/WN) block of 32x32 accumulators; an A/B fragment is one ds_read_b128
 //    (lane (i, h): row i, k = 16 s + 8 h .. + 7).
 //  * Epilogue: accumulators (column on the lane, rows in registers) are transposed through a wave-private slice of
 //    the now idle staging LDS so that global accesses are 16-byte (fp32) / 8-byte (bf16) row-contiguous pieces.
+//
+// gemm_bf16_ring_kernel (8 waves, 256-row tiles; the large GEMMs): measured, the kernel is bound by how many bytes
+// of LDS-DMA a CU keeps in flight (rate = bytes in flight / latency under load, ~2 us), not by instruction issue.  So
+// the k-tile is 32 deep (64-byte rows, chunks swizzled by ((row >> 2) & 3)) and the LDS is a ring of NS such tiles
+// with NS - 1 of them in flight.  Waves 0-3 and 4-7 (SIMD partners) run the same program one barrier interval apart
+// ("ping-pong"): per k-tile a wave LOADS its fragments and issues the DMA of tile t + NS - 1, passes a barrier,
+// COMPUTES 2 x MT x NTL MFMAs at raised priority, passes a barrier; every interval has one wave of each SIMD in its
+// MFMA segment and its partner in its load segment.
+// gemm_bf16_kernel (4 waves, 128x128, BK = 64, two LDS buffers, one barrier per k-tile): small problems.
 #include "bf16.h"
 #include "kernels.h"
 
 int g_gemm_bf16_tile_hint = 0;
+long long* g_gemm_bf16_stamps = nullptr;   // diagnostic: see STAMP in gemm_bf16_ring_kernel
 
 namespace {
 
@@ -42,6 +49,62 @@ struct BTile {
   static_assert(WTM % 32 == 0 && WTN % 32 == 0 && NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
 };
 
+// Transposes the wave's accumulators through its private LDS slice and applies the epilogue.
+template <class T, int EPI>
+__device__ __forceinline__ void epilogue(const GemmBf16Params& p, unsigned char* smem, f32x16 (&acc)[T::MT][T::NTL], int m0, int n0,
+                                         int wave, int lane) {
+  constexpr int MT = T::MT, NTL = T::NTL, WTM = T::WTM, WTN = T::WTN;
+  const int li = lane & 31, h = lane >> 5;
+  const int wr = wave / T::WN, wc = wave % T::WN;
+  float* es = reinterpret_cast<float*>(smem + wave * T::EPW);
+  constexpr int LPR = WTN / 4;        // lanes per output row piece
+  constexpr int RPI = 64 / LPR;       // rows per read instruction
+  const int erow = lane / LPR, ecol = (lane % LPR) * 4;
+  const int gn = n0 + wc * WTN + ecol;
+  const bool ncol = gn < p.N;
+  fx4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && ncol) bias4 = *reinterpret_cast<const fx4*>(p.bias + gn);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < NTL; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) es[((r & 3) + 8 * (r >> 2) + 4 * h) * WTN + j * 32 + li] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 32 / RPI; ++q) {
+      const int lr = q * RPI + erow;
+      fx4 v = *reinterpret_cast<const fx4*>(es + lr * WTN + ecol);
+      const int gm = m0 + wr * WTM + i * 32 + lr;
+      if (gm < p.M && ncol) {
+        v += bias4;
+        const long long crow = p.c_rgrp > 0 ? gm + gm / p.c_rgrp + 1 : gm;
+        if (EPI == BEPI_F32 || EPI == BEPI_F32_PLAIN) {
+          if (EPI == BEPI_F32 && p.res) {
+            const long long rr = p.res_mod > 0 ? (gm % p.res_mod) + 1 : gm;
+            v += *reinterpret_cast<const fx4*>(p.res + rr * p.ldr + gn);
+          }
+          *reinterpret_cast<fx4*>(reinterpret_cast<float*>(p.C) + crow * p.ldc + gn) = v;
+        } else if (EPI == BEPI_BF16) {
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = __builtin_convertvector(v, bf16x4);
+        } else if (EPI == BEPI_GELU_BF16 || EPI == BEPI_GELU2_BF16) {
+          if (EPI == BEPI_GELU2_BF16) *reinterpret_cast<bf16x4*>(p.C2 + (long long)gm * p.ldc2 + gn) = __builtin_convertvector(v, bf16x4);
+          fx4 g = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = __builtin_convertvector(g, bf16x4);
+        } else {  // BEPI_DGELU_BF16
+          const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.aux + (long long)gm * p.ldaux + gn);
+          fx4 g = {v[0] * gelu_erf_grad((float)a[0]), v[1] * gelu_erf_grad((float)a[1]), v[2] * gelu_erf_grad((float)a[2]),
+                   v[3] * gelu_erf_grad((float)a[3])};
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = __builtin_convertvector(g, bf16x4);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ simple kernel
+// BK = 64 (128-byte rows, chunk swizzle ((row >> 1) & 7)), two LDS buffers, one barrier per k-tile.
 template <class T, int EPI>
 __global__ void __launch_bounds__(T::NT) gemm_bf16_kernel(const GemmBf16Params p) {
   constexpr int BM = T::BM, BN = T::BN, NW = T::NW, MT = T::MT, NTL = T::NTL, WTM = T::WTM, WTN = T::WTN;
@@ -53,7 +116,6 @@ __global__ void __launch_bounds__(T::NT) gemm_bf16_kernel(const GemmBf16Params p
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
   const int wr = wave / T::WN, wc = wave % T::WN;
 
-  // ---- LDS-DMA plan ------------------------------------------------------------------------------------
   long long abytes = ((long long)(p.M - 1 - m0) * p.lda + p.K) * 2, bbytes = ((long long)(p.N - 1 - n0) * p.ldb + p.K) * 2;
   if (abytes > 0x7FFFFFF0ll) abytes = 0x7FFFFFF0ll;
   if (bbytes > 0x7FFFFFF0ll) bbytes = 0x7FFFFFF0ll;
@@ -81,7 +143,7 @@ __global__ void __launch_bounds__(T::NT) gemm_bf16_kernel(const GemmBf16Params p
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + BM * 128 + i * NW * 1024), 16, ob + i * stepB, 0, 0, 0);
   };
 
-  // ---- fragment addresses (bytes inside a buffer): row * 128 + ((2 s + h) ^ f(row)) * 16 ------------------
+  // fragment addresses (bytes inside a buffer): row * 128 + ((2 s + h) ^ f(row)) * 16
   const unsigned fsw = (unsigned)((li >> 1) & 7);
   const unsigned a_l0 = (unsigned)(wr * WTM + li) * 128u + ((h ^ fsw) * 16u);
   const unsigned b_l0 = (unsigned)(BM + wc * WTN + li) * 128u + ((h ^ fsw) * 16u);
@@ -115,84 +177,324 @@ __global__ void __launch_bounds__(T::NT) gemm_bf16_kernel(const GemmBf16Params p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-
-  // ---- epilogue -------------------------------------------------------------------------------------------
-  float* es = reinterpret_cast<float*>(smem + wave * T::EPW);
-  constexpr int LPR = WTN / 4;        // lanes per output row piece
-  constexpr int RPI = 64 / LPR;       // rows per read instruction
-  const int erow = lane / LPR, ecol = (lane % LPR) * 4;
-  const int gn = n0 + wc * WTN + ecol;
-  const bool ncol = gn < p.N;
-  fx4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (p.bias && ncol) bias4 = *reinterpret_cast<const fx4*>(p.bias + gn);
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int j = 0; j < NTL; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) es[((r & 3) + 8 * (r >> 2) + 4 * h) * WTN + j * 32 + li] = acc[i][j][r];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int q = 0; q < 32 / RPI; ++q) {
-      const int lr = q * RPI + erow;
-      fx4 v = *reinterpret_cast<const fx4*>(es + lr * WTN + ecol);
-      const int gm = m0 + wr * WTM + i * 32 + lr;
-      if (gm < p.M && ncol) {
-        v += bias4;
-        const long long crow = p.c_rgrp > 0 ? gm + gm / p.c_rgrp + 1 : gm;
-        if (EPI == BEPI_F32 || EPI == BEPI_F32_PLAIN) {
-          if (EPI == BEPI_F32 && p.res) {
-            const long long rr = p.res_mod > 0 ? (gm % p.res_mod) + 1 : gm;
-            v += *reinterpret_cast<const fx4*>(p.res + rr * p.ldr + gn);
-          }
-          *reinterpret_cast<fx4*>(reinterpret_cast<float*>(p.C) + crow * p.ldc + gn) = v;
-        } else if (EPI == BEPI_BF16) {
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = __builtin_convertvector(v, bf16x4);
-        } else if (EPI == BEPI_GELU_BF16) {
-          if (p.C2) *reinterpret_cast<bf16x4*>(p.C2 + (long long)gm * p.ldc2 + gn) = __builtin_convertvector(v, bf16x4);
-          fx4 g = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = __builtin_convertvector(g, bf16x4);
-        } else {  // BEPI_DGELU_BF16
-          const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.aux + (long long)gm * p.ldaux + gn);
-          fx4 g = {v[0] * gelu_erf_grad((float)a[0]), v[1] * gelu_erf_grad((float)a[1]), v[2] * gelu_erf_grad((float)a[2]),
-                   v[3] * gelu_erf_grad((float)a[3])};
-          *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = __builtin_convertvector(g, bf16x4);
-        }
-      }
-    }
-  }
+  epilogue<T, EPI>(p, smem, acc, m0, n0, wave, lane);
 }
 
+// ------------------------------------------------------------------------------------------------ ring kernel
+// Persistent: one 8-wave workgroup per CU walks tiles blockIdx.x, + gridDim.x, ...; BK = 32: a k-tile is (BM + BN)
+// rows x 64 bytes.  The k-tiles of ALL the workgroup's tiles form one continuous stream through a ring of NS LDS
+// slots with D = NS - 1 tiles of LDS-DMA in flight: the loads run D k-tiles ahead of the MFMAs straight across tile
+// boundaries, so a tile's prologue (first loads) hides under the previous tile's last MFMAs and its epilogue stores
+// drain under the next tile's MFMAs.  Measured before this structure (one workgroup per tile, K = 768): prologue
+// 7.3k + epilogue 12k cycles around a 34k-cycle main loop (tools/bf16_stamps.py).
+// Waves 0-3 and 4-7 (SIMD partners) run the same program one barrier interval apart ("ping-pong"):
+//   L(g): ds_read the fragments of stream k-tile g; issue the DMA of k-tile g + D into the slot k-tile g - 1 had;
+//         wait until this wave's share of k-tile g + 1 has landed; wait lgkmcnt(0); barrier.
+//   C(g): 2 x MT x NTL MFMAs at raised priority; barrier.   After the last C of a tile: epilogue (no barrier inside).
+//   WAR: both groups finished L(g-1) (reads retired by lgkmcnt(0)) before a barrier that precedes any L(g).
+//   RAW: a wave's share of k-tile g + 1 is waited for at the end of its L(g), before the barrier that precedes the
+//        other group's and its own L(g + 1).
+//   vmcnt: loads, LDS-DMAs and stores retire in issue order on one counter.  The epilogue's NST stores are issued
+//        AFTER the DMAs of the next D - 1 k-tiles, so for the D - 1 load segments that follow an epilogue the wait
+//        leaves NST more operations outstanding (the stores need not have drained); every store / residual load of the
+//        epilogue is an unconditional buffer instruction (invalid rows / columns go out of range) so NST is exact.
 template <class T, int EPI>
-int launch(const GemmBf16Params& p, hipStream_t st) {
-  static bool attr_done = false;   // the kernels use more than the 64 KB default dynamic LDS limit
-  if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            T::LDS) != hipSuccess)
-      return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit to %d bytes", T::LDS);
-    attr_done = true;
+struct Ring {
+  static constexpr int SLOT = (T::BM + T::BN) * 64;                 // bytes per k-tile
+  static constexpr int EPW = 16 * T::WTN * 4;                       // epilogue staging per wave: 16 rows x WTN fp32
+  static constexpr int NS = ((163840 - 8 * EPW) / SLOT) < 6 ? ((163840 - 8 * EPW) / SLOT) : 6;
+  static constexpr int D = NS - 1;
+  static constexpr int GA = T::BM / 16 / 8, GB = T::BN / 16 / 8;    // DMA instructions per wave and k-tile (16 rows each)
+  static constexpr int PER = GA + GB;
+  static constexpr int LDS = NS * SLOT + 8 * EPW;
+  static constexpr int NST = T::MT * 2 * (16 * T::WTN / 256) * (EPI == BEPI_GELU2_BF16 ? 2 : 1);   // stores per wave and tile
+  static constexpr int WAIT = PER * (D - 1);
+  static constexpr int WAIT_EPI = WAIT + NST <= 63 ? WAIT + NST : WAIT;   // a smaller count only over-waits
+  static_assert(T::NW == 8 && T::BM % 128 == 0 && T::BN % 128 == 0 && NS >= 3, "ring kernel: 8 waves, 128-row multiples");
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+#define DGVIT_BUF_OOB 0x80000000u
+
+// STAMP: diagnostic build (tools/bf16_stamps.py): wave 0 / wave 4 lane 0 of every workgroup write s_memtime at the start
+// of each of its first 8 tiles, after the tile's main loop and after its epilogue, to a buffer nothing else reads.
+// The shipped instantiations have STAMP = false (no stamp executes).
+template <class T, int EPI, bool STAMP = false>
+__global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Params p, int ntiles, long long* stamps = nullptr) {
+  constexpr int BM = T::BM, BN = T::BN, MT = T::MT, NTL = T::NTL, WTM = T::WTM, WTN = T::WTN;
+  using R = Ring<T, EPI>;
+  constexpr int NS = R::NS, D = R::D;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int wr = wave / T::WN, wc = wave % T::WN;
+  const int nkt = (p.K + 31) / 32;
+
+  // ---- load side: runs D k-tiles ahead of the compute side, across tile boundaries ---------------------------
+  // one DMA instruction fills 16 rows x 64 bytes: lane -> row lane >> 2, physical chunk lane & 3, which holds logical
+  // chunk (lane & 3) ^ ((row >> 2) & 3); 16-row groups keep (row >> 2) & 3 == (lane >> 4) & 3
+  const int srow = lane >> 2;
+  const int sc = (lane & 3) ^ ((lane >> 4) & 3);
+  const unsigned offA = ((unsigned)(wave * 16 + srow) * (unsigned)p.lda + sc * 8u) * 2u;
+  const unsigned offB = ((unsigned)(wave * 16 + srow) * (unsigned)p.ldb + sc * 8u) * 2u;
+  const unsigned stepA = 128u * (unsigned)p.lda * 2u, stepB = 128u * (unsigned)p.ldb * 2u;   // 8 waves x 16 rows
+  int ltile = blockIdx.x, lt = 0, lslot = 0;
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  auto set_load_tile = [&](int v) {
+    const int tile = xcd_chunk(v, ntiles);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    long long abytes = ((long long)(p.M - 1 - m0) * p.lda + p.K) * 2, bbytes = ((long long)(p.N - 1 - n0) * p.ldb + p.K) * 2;
+    if (abytes > 0x7FFFFFF0ll) abytes = 0x7FFFFFF0ll;
+    if (bbytes > 0x7FFFFFF0ll) bbytes = 0x7FFFFFF0ll;
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + (long long)m0 * p.lda), 0, (int)abytes, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B + (long long)n0 * p.ldb), 0, (int)bbytes, 0x00020000);
+  };
+  set_load_tile(ltile);   // blockIdx.x < ntiles by construction of the grid
+  auto issue_next = [&]() {
+    // past the last tile the same instructions still issue (every lane out of range, zeros into a free slot): the
+    // vmcnt bookkeeping then is the same for every stream length
+    const unsigned dead = (ltile < ntiles && lt * 32 + sc * 8 < p.K) ? 0u : DGVIT_BUF_OOB;
+    const unsigned oa = (offA + (unsigned)lt * 64u) | dead, ob = (offB + (unsigned)lt * 64u) | dead;
+    unsigned char* dst = smem + lslot * R::SLOT + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < R::GA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + i * 8192), 16, oa + i * stepA, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < R::GB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + BM * 64 + i * 8192), 16, ob + i * stepB, 0, 0, 0);
+    lslot = lslot + 1 == NS ? 0 : lslot + 1;
+    if (++lt == nkt) {
+      lt = 0;
+      ltile += gridDim.x;
+      if (ltile < ntiles) set_load_tile(ltile);
+    }
+  };
+
+  // ---- compute side -------------------------------------------------------------------------------------------
+  // fragment addresses inside a slot: row * 64 + ((2 s + h) ^ ((row >> 2) & 3)) * 16,  s = k-step 0 / 1
+  const unsigned fsw = (unsigned)((li >> 2) & 3);
+  const unsigned a_l0 = (unsigned)(wr * WTM + li) * 64u + ((h ^ fsw) * 16u);
+  const unsigned b_l0 = (unsigned)(BM + wc * WTN + li) * 64u + ((h ^ fsw) * 16u);
+  float* es = reinterpret_cast<float*>(smem + NS * R::SLOT + wave * R::EPW);
+  constexpr int LPR = WTN / 4, RPI = 64 / LPR;   // lanes per output row piece, rows per staging read
+  const int erow = lane / LPR, ecol = (lane % LPR) * 4;
+
+  f32x16 acc[MT][NTL];
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int ctile = blockIdx.x, ct = 0, cslot = 0, since_epi = D, ntile_done = 0;
+  long long st0 = 0;
+  if constexpr (STAMP) st0 = __builtin_amdgcn_s_memtime();
+
+#pragma unroll
+  for (int t = 0; t < D; ++t) issue_next();
+  wait_vmcnt<R::WAIT>();
+  __builtin_amdgcn_s_barrier();
+  const int grp = wave >> 2;
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  while (ctile < ntiles) {
+    const unsigned char* sb = smem + cslot * R::SLOT;
+    bf16x8 af[2][MT], bf[2][NTL];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(sb + (a_l0 ^ (s * 32u)) + i * 2048);
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) bf[s][j] = *reinterpret_cast<const bf16x8*>(sb + (b_l0 ^ (s * 32u)) + j * 2048);
+    }
+    issue_next();
+    if (since_epi < D - 1) wait_vmcnt<R::WAIT_EPI>(); else wait_vmcnt<R::WAIT>();
+    ++since_epi;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    if (ct == 0) {   // first k-tile of an output tile: accumulate onto zero (no 128-register clear)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], zero16, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    cslot = cslot + 1 == NS ? 0 : cslot + 1;
+    if (++ct < nkt) continue;
+
+    // ---- epilogue of tile `ctile`: acc (column on the lane, rows in registers) -> wave-private LDS -> row pieces ----
+    long long st1 = 0;
+    if constexpr (STAMP) st1 = __builtin_amdgcn_s_memtime();
+    {
+      const int tile = xcd_chunk(ctile, ntiles);
+      const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+      const int gn = n0 + wc * WTN + ecol;
+      const bool ncol = gn < p.N;
+      // tile-relative buffer addressing: offsets stay small, invalid rows / columns are sent out of range
+      const long long crow0 = p.c_rgrp > 0 ? m0 + m0 / p.c_rgrp + 1 : m0;
+      constexpr int CES = (EPI == BEPI_F32 || EPI == BEPI_F32_PLAIN) ? 4 : 2;
+      const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<unsigned char*>(p.C) + (crow0 * p.ldc + n0) * CES, 0, (int)DGVIT_BUF_OOB, 0x00020000);
+      __amdgpu_buffer_rsrc_t rsX = rsC;   // second operand of the epilogue: residual (fp32) / pre-activation copy / aux (bf16)
+      if (EPI == BEPI_F32 && p.res)
+        rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res) + ((long long)(p.res_mod > 0 ? 0 : m0) * p.ldr + n0), 0,
+                                                (int)DGVIT_BUF_OOB, 0x00020000);
+      if (EPI == BEPI_GELU2_BF16)
+        rsX = __builtin_amdgcn_make_buffer_rsrc(p.C2 + ((long long)m0 * p.ldc2 + n0), 0, (int)DGVIT_BUF_OOB, 0x00020000);
+      if (EPI == BEPI_DGELU_BF16)
+        rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.aux) + ((long long)m0 * p.ldaux + n0), 0, (int)DGVIT_BUF_OOB,
+                                                0x00020000);
+      fx4 bias4 = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && ncol) bias4 = *reinterpret_cast<const fx4*>(p.bias + gn);
+      const unsigned coln = (unsigned)(wc * WTN + ecol);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int j = 0; j < NTL; ++j)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) es[((r & 3) + 8 * (r >> 2) + 4 * h) * WTN + j * 32 + li] = acc[i][j][8 * half + r];
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int q = 0; q < 16 / RPI; ++q) {
+            const int lr = q * RPI + erow;
+            fx4 v = *reinterpret_cast<const fx4*>(es + lr * WTN + ecol);
+            const int ml = wr * WTM + i * 32 + half * 16 + lr, gm = m0 + ml;   // row inside the tile / global
+            const bool ok = gm < p.M && ncol;
+            v += bias4;
+            const long long crow = p.c_rgrp > 0 ? gm + gm / p.c_rgrp + 1 : gm;
+            const unsigned coff = ok ? ((unsigned)(crow - crow0) * (unsigned)p.ldc + coln) * CES : DGVIT_BUF_OOB;
+            if (EPI == BEPI_F32 || EPI == BEPI_F32_PLAIN) {
+              if (EPI == BEPI_F32 && p.res) {
+                const unsigned rr = p.res_mod > 0 ? (unsigned)(gm % p.res_mod) + 1u : (unsigned)ml;
+                const unsigned roff = ok ? (rr * (unsigned)p.ldr + coln) * 4u : DGVIT_BUF_OOB;
+                v += __builtin_bit_cast(fx4, __builtin_amdgcn_raw_buffer_load_b128(rsX, roff, 0, 0));
+              }
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), rsC, coff, 0, 0);
+            } else if (EPI == BEPI_BF16) {
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(v, bf16x4)), rsC, coff, 0, 0);
+            } else if (EPI == BEPI_GELU_BF16 || EPI == BEPI_GELU2_BF16) {
+              if (EPI == BEPI_GELU2_BF16) {
+                const unsigned xoff = ok ? ((unsigned)ml * (unsigned)p.ldc2 + coln) * 2u : DGVIT_BUF_OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(v, bf16x4)), rsX, xoff, 0, 0);
+              }
+              fx4 g = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(g, bf16x4)), rsC, coff, 0, 0);
+            } else {  // BEPI_DGELU_BF16
+              const unsigned xoff = ok ? ((unsigned)ml * (unsigned)p.ldaux + coln) * 2u : DGVIT_BUF_OOB;
+              const bf16x4 a = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rsX, xoff, 0, 0));
+              fx4 g = {v[0] * gelu_erf_grad((float)a[0]), v[1] * gelu_erf_grad((float)a[1]), v[2] * gelu_erf_grad((float)a[2]),
+                       v[3] * gelu_erf_grad((float)a[3])};
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(g, bf16x4)), rsC, coff, 0, 0);
+            }
+          }
+        }
+    }
+    if constexpr (STAMP) {
+      if (lane == 0 && (wave & 3) == 0 && ntile_done < 8) {
+        long long* o = stamps + (((long long)blockIdx.x * 2 + grp) * 8 + ntile_done) * 4;
+        o[0] = st0; o[1] = st1; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+      }
+      st0 = __builtin_amdgcn_s_memtime();
+    }
+    ++ntile_done;
+    ct = 0;
+    since_epi = 0;
+    ctile += gridDim.x;
   }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  wait_vmcnt<0>();   // the trailing (all-zero) LDS-DMAs must land before the workgroup gives its LDS back
+}
+
+int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+template <class T, int EPI, bool RING>
+int launch(const GemmBf16Params& p, hipStream_t st) {
   const long long tiles = (long long)((p.M + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN);
-  const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, st);
-  hipLaunchKernelGGL((gemm_bf16_kernel<T, EPI>), dim3((unsigned)tiles), dim3(T::NT), T::LDS, st, p);
-  profile_end(slot, st);
+  DGVIT_CHECK_ARG(tiles < (1ll << 30), "gemm_bf16: too many tiles");
+  static bool attr_done = false;   // the kernels use more than the 64 KB default dynamic LDS limit
+  if constexpr (RING) {
+    constexpr int LDS = Ring<T, EPI>::LDS;
+    // tile-relative 32-bit buffer offsets in the epilogue
+    DGVIT_CHECK_ARG((long long)(T::BM + T::BM / (p.c_rgrp > 0 ? p.c_rgrp : T::BM) + 2) * p.ldc * 4 < (1ll << 31) &&
+                        (long long)(p.res_mod > 0 ? p.res_mod + 1 : T::BM) * p.ldr * 4 < (1ll << 31) &&
+                        (long long)T::BM * p.ldc2 * 2 < (1ll << 31) && (long long)T::BM * p.ldaux * 2 < (1ll << 31),
+                    "gemm_bf16: output leading dimension too large");
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              LDS) != hipSuccess)
+        return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit to %d bytes", LDS);
+      attr_done = true;
+    }
+    const int grid = (int)(tiles < num_cus() ? tiles : num_cus());   // one persistent workgroup per CU
+    if constexpr (EPI == BEPI_BF16) {
+      if (g_gemm_bf16_stamps) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<T, EPI, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+          return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit");
+        hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI, true>), dim3(grid), dim3(512), LDS, st, p, (int)tiles, g_gemm_bf16_stamps);
+        DGVIT_CHECK_LAUNCH("gemm_bf16_ring_kernel(stamps)");
+        return DGVIT_OK;
+      }
+    }
+    const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, st);
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI>), dim3(grid), dim3(512), LDS, st, p, (int)tiles, (long long*)nullptr);
+    profile_end(slot, st);
+  } else {
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              T::LDS) != hipSuccess)
+        return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit to %d bytes", T::LDS);
+      attr_done = true;
+    }
+    const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, st);
+    hipLaunchKernelGGL((gemm_bf16_kernel<T, EPI>), dim3((unsigned)tiles), dim3(T::NT), T::LDS, st, p);
+    profile_end(slot, st);
+  }
   DGVIT_CHECK_LAUNCH("gemm_bf16_kernel");
   return DGVIT_OK;
 }
 
 template <int EPI>
 int dispatch(const GemmBf16Params& p, hipStream_t st) {
-  // tile choice: 256x256 (8 waves) when the grid still fills the chip several times over, else 128x128 (4 waves)
+  // tile choice: 256x256 ring kernel when the grid still fills the chip, else the 128x128 simple kernel
   int tile = g_gemm_bf16_tile_hint;
   if (!tile) {
     const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     tile = (p.M >= 256 && p.N >= 256 && t256 >= 512) ? 256256 : 128128;
   }
   switch (tile) {
-    case 256256: return launch<BTile<256, 256, 2, 4>, EPI>(p, st);
-    case 256128: return launch<BTile<256, 128, 4, 2>, EPI>(p, st);
-    case 128128: return launch<BTile<128, 128, 2, 2>, EPI>(p, st);
+    case 256256: return launch<BTile<256, 256, 2, 4>, EPI, true>(p, st);
+    case 256128: return launch<BTile<256, 128, 4, 2>, EPI, true>(p, st);
+    case 128128: return launch<BTile<128, 128, 2, 2>, EPI, false>(p, st);
     default: return dgvit_set_error(DGVIT_ERR_ARG, "gemm_bf16: unknown tile %d", tile);
   }
 }
@@ -203,7 +505,9 @@ int gemm_bf16(int epi, const GemmBf16Params& p, hipStream_t st) {
   DGVIT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm_bf16: empty problem %d x %d x %d", p.M, p.N, p.K);
   DGVIT_CHECK_ARG(p.K % 8 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0, "gemm_bf16: K, lda, ldb must be multiples of 8 (16-byte rows)");
   DGVIT_CHECK_ARG(p.N % 4 == 0 && p.ldc % 4 == 0, "gemm_bf16: N and ldc must be multiples of 4");
-  DGVIT_CHECK_ARG(((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C) % 16 == 0, "gemm_bf16: operands must be 16-byte aligned");
+  DGVIT_CHECK_ARG(((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.C2 | (uintptr_t)p.aux) % 16 == 0,
+                  "gemm_bf16: operands must be 16-byte aligned");
+  DGVIT_CHECK_ARG((!p.res || p.ldr % 4 == 0) && (epi != BEPI_DGELU_BF16 || (p.aux && p.ldaux % 4 == 0)), "gemm_bf16: bad residual / aux");
   DGVIT_CHECK_ARG((long long)p.lda * 2 * 256 < (1ll << 30) && (long long)p.ldb * 2 * 256 < (1ll << 30), "gemm_bf16: leading dimension too large");
   switch (epi) {
     case BEPI_BF16: return dispatch<BEPI_BF16>(p, st);
@@ -211,6 +515,9 @@ int gemm_bf16(int epi, const GemmBf16Params& p, hipStream_t st) {
     case BEPI_F32: return dispatch<BEPI_F32>(p, st);
     case BEPI_DGELU_BF16: return dispatch<BEPI_DGELU_BF16>(p, st);
     case BEPI_F32_PLAIN: return dispatch<BEPI_F32_PLAIN>(p, st);
+    case BEPI_GELU2_BF16:
+      DGVIT_CHECK_ARG(p.C2 && p.ldc2 % 4 == 0, "gemm_bf16: epilogue 5 needs C2");
+      return dispatch<BEPI_GELU2_BF16>(p, st);
     default: return dgvit_set_error(DGVIT_ERR_ARG, "gemm_bf16: unknown epilogue %d", epi);
   }
 }

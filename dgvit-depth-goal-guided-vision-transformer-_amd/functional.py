@@ -328,6 +328,8 @@ def op_gemm_bf16(epilogue, a, b, bias=None, res=None, aux=None, want_c2=False):
     bias = None if bias is None else _dev(bias, "bias")
     res = None if res is None else _dev(res, "res")
     aux = None if aux is None else _dev_bf16(aux, "aux")
+    if want_c2:
+        epilogue = 5    # GELU with the pre-activation copy
     with torch.cuda.device(a.device):
         rc = lib.dgvit_gemm_bf16(int(epilogue), _ptr(a), K, _ptr(b), K, _ptr(c), N, M, N, K, _ptr(bias), _ptr(res), N, _ptr(c2), N,
                                  _ptr(aux), N, _stream())

@@ -219,13 +219,17 @@ int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* const* params, 
 /* operator-level entry points of the bf16 kernels (parity tests, benches) */
 int dgvit_cast_f32_bf16(const float* src, unsigned short* dst, long long n, void* stream);
 /* C = A B^T (+ epilogue), A (M,K) / B (N,K) bf16 with k contiguous, K, lda, ldb % 8 == 0, N, ldc % 4 == 0.
- * epilogue 0: C bf16 = acc + bias;  1: C bf16 = gelu(acc + bias), C2 bf16 = acc + bias (optional);
- *          2: C fp32 = acc + bias + res (fp32);  3: C bf16 = acc * gelu'(aux bf16);  4: C fp32 = acc. */
+ * epilogue 0: C bf16 = acc + bias;  1: C bf16 = gelu(acc + bias);  2: C fp32 = acc + bias + res (fp32);
+ *          3: C bf16 = acc * gelu'(aux bf16);  4: C fp32 = acc;  5: as 1 and C2 bf16 = acc + bias (pre-activation). */
 int dgvit_gemm_bf16(int epilogue, const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, int M,
                     int N, int K, const float* bias, const float* res, int ldr, unsigned short* C2, int ldc2,
                     const unsigned short* aux, int ldaux, void* stream);
 /* test/bench knob: force the bf16 GEMM workgroup tile (0 = automatic; 256256, 256128, 128128) */
 void dgvit_set_gemm_bf16_tile(int tile);
+/* diagnostic (tools/bf16_stamps.py): non-NULL = the epilogue-0 ring GEMM runs its stamped build and writes, per workgroup,
+ * 2 wave groups x 8 tiles x 4 int64 {s_memtime at tile start / after its main loop / after its epilogue, s_memrealtime}
+ * to this device buffer (256 workgroups at most); NULL (default) = shipped kernels, no stamp executes. */
+void dgvit_set_gemm_bf16_stamps(long long* stamps);
 /* LayerNorm with fp32 input and bf16 output (mean / rstd may be NULL) */
 int dgvit_layernorm_forward_bf16(const float* x, const float* gamma, const float* beta, unsigned short* y, float* mean,
                                  float* rstd, int rows, int D, void* stream);
