@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 256 CUs @ 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA dense (the 2:1-sparsity headline figure is never used)
 IMAGE, PATCH, DIM, DEPTH, HEADS = (84, 84), (12, 12), 256, 6, 8
 
 
@@ -38,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--no-sac-step", action="store_true", help="skip the secondary full SAC-style step measurement")
+    ap.add_argument("--no-c5", action="store_true", help="skip the secondary config-5 (224x224 ViT-Base, bf16) forward measurement")
     ap.add_argument("--wgrad-overlap", action="store_true", help="A/B: weight-gradient GEMMs on the helper stream (+5%% frames/s, blurs per-kernel timing)")
     ap.add_argument("--dense-last-block", action="store_true", help="A/B: compute the last block for every token")
     return ap.parse_args()
@@ -118,6 +120,40 @@ def sac_step(dgvit_amd, synthetic, B, dev, steps=5):
     dt = (time.perf_counter() - t0) / steps
     return {"ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(B / dt, 1), "encoder_passes": "5 fwd + 3 bwd per frame",
             "note": "transformer actor + transformer critic, DRL.py:390-432 arithmetic"}
+
+
+def c5_bf16(dgvit_amd, lib, _lib, dev, batch=256, steps=10):
+    """Secondary number: BASELINE config 5 (224x224 depth frames, 12-layer ViT-Base variant with goal token, bf16 storage /
+    fp32 accumulate), forward only, one GPU.  FLOPs per frame: SURVEY 8(d) dense figure (34.972 GFLOP)."""
+    import synthetic
+    torch.manual_seed(5)
+    m = dgvit_amd.GoT(image_size=224, patch_size=16, num_classes=2, dim=768, depth=12, heads=12, mlp_dim=3072, channels=1)
+    m = m.to(dev).eval().set_compute_dtype(torch.bfloat16)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    img, goal = torch.rand(batch, 224, 224, generator=g).to(dev), torch.randn(batch, 768, generator=g).to(dev)
+    with torch.no_grad():
+        for _ in range(3):
+            m(img, goal)
+        torch.cuda.synchronize()
+        lib.dgvit_profile_start(4096)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m(img, goal)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    kinds = _lib.PROFILE_KINDS
+    ms, work, cnt = (ctypes.c_double * kinds)(), (ctypes.c_double * kinds)(), (ctypes.c_longlong * kinds)()
+    lib.dgvit_profile_stop(ms, work, cnt)
+    fwd = synthetic.fwd_flops_per_frame((224, 224), (16, 16), 768, 12, 12, mlp_dim=3072)
+    gemm_tf = (work[0] / 1e12) / (ms[0] / 1e3) if ms[0] > 0 else 0.0
+    return {"workload": f"C5: GoT 224x224@16x16, L12 H12 D768 M3072 (N=197), forward, batch {batch}, bf16 storage / fp32 accumulate",
+            "frames_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "dtype": "bf16",
+            "tflops_dense": round(batch / dt * fwd / 1e12, 1), "frac_of_bf16_peak": round(batch / dt * fwd / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_ring_kernel", "achieved": round(gemm_tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(gemm_tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                         "avg_launch_ms": round(ms[0] / max(1, cnt[0]), 5), "launches_per_step": int(cnt[0] // steps)},
+            "gemm_ms_per_step": round(ms[0] / steps, 3), "attn_fwd_ms_per_step": round(ms[1] / steps, 3),
+            "norm_ms_per_step": round(ms[3] / steps, 3)}
 
 
 def main():
@@ -238,6 +274,8 @@ def main():
         }
         if world == 1 and not args.no_sac_step:
             out["sac_step"] = sac_step(dgvit_amd, synthetic, B, dev)
+        if world == 1 and not args.no_c5:
+            out["c5_bf16"] = c5_bf16(dgvit_amd, lib, _lib, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(out), flush=True)

@@ -40,6 +40,9 @@ int cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t st);
 int patchify_bf16(const float* img, bf16_t* patches, int B, int ih, int iw, int ph, int pw, hipStream_t st);
 int layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int T, int D,
                        float eps, int rs, hipStream_t st);
+int add_layernorm_fwd_bf16(const float* x, const bf16_t* delta, float* xout, const float* gamma, const float* beta, bf16_t* y,
+                           float* mean, float* rstd, int T, int D, float eps, int rs, hipStream_t st);
+int residual_add_bf16(const float* x, const bf16_t* delta, float* xout, int rows, int D, int rs, hipStream_t st);
 int attention_fwd_bf16(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N, int H, int dh, int nq, hipStream_t st);
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }

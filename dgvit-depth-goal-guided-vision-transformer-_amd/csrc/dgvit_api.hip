@@ -705,7 +705,7 @@ Wp make_wp(const Dims& d) {
 // activation workspace in BYTES
 struct Wsb {
   long long patches, xa, xb, pooled, layer0, layer_stride, total;
-  long long ln, qkv, ao, lse, xmid, a1, layer_bytes;   // relative to the layer base
+  long long ln, qkv, ao, lse, xmid, a1, delta, layer_bytes;   // relative to the layer base
 };
 Wsb make_wsb(const Dims& d, int save) {
   Wsb w;
@@ -721,6 +721,7 @@ Wsb make_wsb(const Dims& d, int save) {
   w.lse = l; l += al128((long long)d.B * d.H * d.N * 4);
   w.xmid = l; l += al128(d.T * d.D * 4);
   w.a1 = l; l += al128(d.T * d.M * 2);
+  w.delta = l; l += al128(d.T * d.D * 2);   // bf16 branch output (attention / feed-forward) before it joins the fp32 residual stream
   w.layer0 = o; w.layer_bytes = l;
   w.layer_stride = save ? l : 0;
   o += save ? l * d.L : l;
@@ -812,6 +813,11 @@ extern "C" int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* cons
   TRY(goal_row(goal, params[P_POS], x, d.B, d.N, d.D, st));
   if (keep < 1.f) TRY(dropout_inplace(x, d.T * d.D, seed, seed_dev, keep, st));
 
+  // The branch outputs (to_out, fc2: GoalFormer.py:82,49) are stored bf16 like every other GEMM output and join the fp32
+  // residual stream inside the LayerNorm kernel of the next sub-block (x = attn(..) + x; x = ff(..) + x, :103-104): the GEMM
+  // epilogues then have no fp32 residual read on their critical path.
+  TRY(layernorm_fwd_bf16(x, params[P_L0 + L_LN1W], params[P_L0 + L_LN1B], (bf16_t*)(ws + w.layer0 + w.ln), nullptr, nullptr, T, d.D,
+                         1e-5f, 1, st));
   for (int i = 0; i < d.L; ++i) {
     const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
     const bf16_t* lw = wpack + wp.layer0 + wp.layer_elems * i;
@@ -821,9 +827,9 @@ extern "C" int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* cons
     bf16_t* ao = (bf16_t*)(lb + w.ao);
     float* xmid = (float*)(lb + w.xmid);
     bf16_t* a1 = (bf16_t*)(lb + w.a1);
+    bf16_t* delta = (bf16_t*)(lb + w.delta);
     const bool last = g_prune_last && !d.pool_mean && i == d.L - 1;   // see dgvit_got_forward
     const int tok = last ? d.B : T, rs = last ? d.N : 1;
-    TRY(layernorm_fwd_bf16(x, lp[L_LN1W], lp[L_LN1B], ln, nullptr, nullptr, T, d.D, 1e-5f, 1, st));
     if (!last) {
       GemmBf16Params p = gpb(ln, d.D, lw + wp.qkv, d.D, qkv, 3 * d.I, T, 3 * d.I, d.D);
       TRY(gemm_bf16(BEPI_BF16, p, st));
@@ -835,20 +841,29 @@ extern "C" int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* cons
     }
     TRY(attention_fwd_bf16(qkv, ao, nullptr, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
     {
-      GemmBf16Params p = gpb(ao, rs * d.I, lw + wp.out, d.I, xmid, rs * d.D, tok, d.D, d.I);
-      p.bias = lp[L_OUTB]; p.res = x; p.ldr = rs * d.D;
-      TRY(gemm_bf16(BEPI_F32, p, st));
+      GemmBf16Params p = gpb(ao, rs * d.I, lw + wp.out, d.I, delta, rs * d.D, tok, d.D, d.I);
+      p.bias = lp[L_OUTB];
+      TRY(gemm_bf16(BEPI_BF16, p, st));
     }
-    TRY(layernorm_fwd_bf16(xmid, lp[L_LN2W], lp[L_LN2B], ln, nullptr, nullptr, tok, d.D, 1e-5f, rs, st));
+    // xmid = x + to_out(..);  ln = LN2(xmid)
+    TRY(add_layernorm_fwd_bf16(x, delta, xmid, lp[L_LN2W], lp[L_LN2B], ln, nullptr, nullptr, tok, d.D, 1e-5f, rs, st));
     {
       GemmBf16Params p = gpb(ln, rs * d.D, lw + wp.fc1, d.D, a1, d.M, tok, d.M, d.D);
       p.bias = lp[L_FC1B];
       TRY(gemm_bf16(BEPI_GELU_BF16, p, st));
     }
     {
-      GemmBf16Params p = gpb(a1, d.M, lw + wp.fc2, d.M, xnext, rs * d.D, tok, d.D, d.M);
-      p.bias = lp[L_FC2B]; p.res = xmid; p.ldr = rs * d.D;
-      TRY(gemm_bf16(BEPI_F32, p, st));
+      GemmBf16Params p = gpb(a1, d.M, lw + wp.fc2, d.M, delta, rs * d.D, tok, d.D, d.M);
+      p.bias = lp[L_FC2B];
+      TRY(gemm_bf16(BEPI_BF16, p, st));
+    }
+    // xnext = xmid + ff(..), and the next block's LN1 of it
+    if (i + 1 < d.L) {
+      unsigned char* nb = ws + w.layer0 + w.layer_stride * (i + 1);
+      TRY(add_layernorm_fwd_bf16(xmid, delta, xnext, lp[DGVIT_PARAMS_PER_LAYER + L_LN1W], lp[DGVIT_PARAMS_PER_LAYER + L_LN1B],
+                                 (bf16_t*)(nb + w.ln), nullptr, nullptr, T, d.D, 1e-5f, 1, st));
+    } else {
+      TRY(residual_add_bf16(xmid, delta, xnext, tok, d.D, rs, st));
     }
     std::swap(x, xnext);
   }

@@ -28,9 +28,12 @@ __global__ void __launch_bounds__(256) patchify_bf16_kernel(const float* __restr
   out[idx] = __builtin_bit_cast(bf16_t, v);
 }
 
-// nn.LayerNorm(D), eps 1e-5 (GoalFormer.py:34,37): fp32 row in, bf16 row out; one wave per row, row kept in registers
-template <int NCH>
-__global__ void __launch_bounds__(256) layernorm_fwd_bf16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+// nn.LayerNorm(D), eps 1e-5 (GoalFormer.py:34,37): fp32 row in, bf16 row out; one wave per row, row kept in registers.
+// ADD: the row is first completed with the bf16 branch output of the previous sub-block (GoalFormer.py:103-104:
+// x = attn(..) + x / x = ff(..) + x): v = x + delta, written back to the fp32 residual stream `xout`.
+template <int NCH, bool ADD>
+__global__ void __launch_bounds__(256) layernorm_fwd_bf16_kernel(const float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                                 float* __restrict__ xout, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                                  float* __restrict__ mean, float* __restrict__ rstd, int T, int D,
                                                                  float eps, int rs) {
@@ -44,7 +47,13 @@ __global__ void __launch_bounds__(256) layernorm_fwd_bf16_kernel(const float* __
   for (int i = 0; i < NCH; ++i) {
     const int c = lane * 4 + i * 256;
     v[i] = fx4{0.f, 0.f, 0.f, 0.f};
-    if (c < D) v[i] = *reinterpret_cast<const fx4*>(xr + c);
+    if (c < D) {
+      v[i] = *reinterpret_cast<const fx4*>(xr + c);
+      if (ADD) {
+        v[i] += __builtin_convertvector(*reinterpret_cast<const bf16x4*>(delta + (long long)row * rs * D + c), fx4);
+        *reinterpret_cast<fx4*>(xout + (long long)row * rs * D + c) = v[i];
+      }
+    }
     s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   }
   const float mu = wave_sum(s) / (float)D;
@@ -75,7 +84,28 @@ __global__ void __launch_bounds__(256) layernorm_fwd_bf16_kernel(const float* __
   }
 }
 
+// xout = x + delta on `rows` rows of D (row r at r * rs * D): the last residual add of the encoder
+__global__ void __launch_bounds__(256) residual_add_bf16_kernel(const float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                                float* __restrict__ xout, long long rows, int D4, long long stride) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * D4) return;
+  const long long r = i / D4, off = r * stride + (i % D4) * 4;
+  *reinterpret_cast<fx4*>(xout + off) =
+      *reinterpret_cast<const fx4*>(x + off) + __builtin_convertvector(*reinterpret_cast<const bf16x4*>(delta + off), fx4);
+}
+
 }  // namespace
+
+int residual_add_bf16(const float* x, const bf16_t* delta, float* xout, int rows, int D, int rs, hipStream_t st) {
+  DGVIT_CHECK_ARG(x && delta && xout && rows > 0 && D > 0 && D % 4 == 0, "residual_add_bf16: bad arguments");
+  const long long n4 = (long long)rows * (D / 4);
+  const int slot = profile_begin(PROF_OTHER, 0.0, st);
+  hipLaunchKernelGGL(residual_add_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, delta, xout, (long long)rows,
+                     D / 4, (long long)rs * D);
+  profile_end(slot, st);
+  DGVIT_CHECK_LAUNCH("residual_add_bf16");
+  return DGVIT_OK;
+}
 
 int cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t st) {
   DGVIT_CHECK_ARG(src && dst && n > 0 && n % 4 == 0, "cast_f32_bf16: n must be a positive multiple of 4");
@@ -94,19 +124,31 @@ int patchify_bf16(const float* img, bf16_t* out, int B, int Hi, int Wi, int ph, 
   return DGVIT_OK;
 }
 
-int layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int T, int D,
-                       float eps, int rs, hipStream_t st) {
+template <bool ADD>
+static int layernorm_launch(const float* x, const bf16_t* delta, float* xout, const float* gamma, const float* beta, bf16_t* y,
+                            float* mean, float* rstd, int T, int D, float eps, int rs, hipStream_t st) {
   DGVIT_CHECK_ARG(x && gamma && beta && y && T > 0, "layernorm_bf16: bad arguments");
   DGVIT_CHECK_ARG(D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bf16: D=%d must be a multiple of 4 and <= 1024", D);
   const int slot = profile_begin(PROF_OTHER, 0.0, st);
   const dim3 grid((unsigned)((T + 3) / 4)), blk(256);
   if (D <= 256)
-    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<1>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, T, D, eps, rs);
+    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<1, ADD>), grid, blk, 0, st, x, delta, xout, gamma, beta, y, mean, rstd, T, D, eps, rs);
   else if (D <= 512)
-    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<2>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, T, D, eps, rs);
+    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<2, ADD>), grid, blk, 0, st, x, delta, xout, gamma, beta, y, mean, rstd, T, D, eps, rs);
   else
-    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<4>), grid, blk, 0, st, x, gamma, beta, y, mean, rstd, T, D, eps, rs);
+    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<4, ADD>), grid, blk, 0, st, x, delta, xout, gamma, beta, y, mean, rstd, T, D, eps, rs);
   profile_end(slot, st);
   DGVIT_CHECK_LAUNCH("layernorm_fwd_bf16");
   return DGVIT_OK;
+}
+
+int layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int T, int D,
+                       float eps, int rs, hipStream_t st) {
+  return layernorm_launch<false>(x, nullptr, nullptr, gamma, beta, y, mean, rstd, T, D, eps, rs, st);
+}
+
+int add_layernorm_fwd_bf16(const float* x, const bf16_t* delta, float* xout, const float* gamma, const float* beta, bf16_t* y,
+                           float* mean, float* rstd, int T, int D, float eps, int rs, hipStream_t st) {
+  DGVIT_CHECK_ARG(delta && xout, "add_layernorm_bf16: bad arguments");
+  return layernorm_launch<true>(x, delta, xout, gamma, beta, y, mean, rstd, T, D, eps, rs, st);
 }

@@ -313,7 +313,7 @@ def got_forward(p: Dict[str, Tensor], img: Tensor, goal: Tensor, cfg: GoTConfig,
 # --------------------------------------------------------------------------
 # bf16 configuration (BASELINE config 5): the same GoT.forward with the STORAGE roundings of the HIP bf16 path
 # modelled (every GEMM operand -- patches, LayerNorm outputs, q/k/v, attention probabilities and output, GELU
-# output, the GEMM weights -- rounded to bf16; residual stream, statistics, biases, softmax and all sums in the
+# output, the to_out / fc2 branch outputs, the GEMM weights -- rounded to bf16; residual stream, statistics, biases, softmax and all sums in the
 # working dtype).  Pinned two ways in tests/: against the fp32 restatement above (distance = the precision cost of
 # bf16 storage) and against the reference run under torch.autocast(bfloat16) (tests/golden/make_golden_bf16.py).
 # --------------------------------------------------------------------------
@@ -343,10 +343,10 @@ def got_forward_bf16(p: Dict[str, Tensor], img: Tensor, goal: Tensor, cfg: GoTCo
         e = torch.exp(dots - dots.amax(-1, keepdim=True))
         out = (rb(e) @ v) / e.sum(-1, keepdim=True)                           # :77-80 (probabilities stored bf16, sum fp32)
         out = rb(out.permute(0, 2, 1, 3).reshape(B, N, I))                    # :81
-        x = linear(out, rb(p[lp + "0.fn.to_out.0.weight"]), p[lp + "0.fn.to_out.0.bias"]) + x
+        x = rb(linear(out, rb(p[lp + "0.fn.to_out.0.weight"]), p[lp + "0.fn.to_out.0.bias"])) + x   # branch output stored bf16
         h = rb(layer_norm(x, p[lp + "1.norm.weight"], p[lp + "1.norm.bias"]))
         a = rb(gelu_exact(linear(h, rb(p[lp + "1.fn.net.0.weight"]), p[lp + "1.fn.net.0.bias"])))
-        x = linear(a, rb(p[lp + "1.fn.net.3.weight"]), p[lp + "1.fn.net.3.bias"]) + x
+        x = rb(linear(a, rb(p[lp + "1.fn.net.3.weight"]), p[lp + "1.fn.net.3.bias"])) + x
     pooled = x.mean(dim=1) if pool == "mean" else x[:, 0]                     # :167
     return rms_norm(pooled, p[prefix + "layer_norm.g"])                       # :170
 

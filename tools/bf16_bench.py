@@ -40,7 +40,7 @@ def main():
     B, N, D, I, M = a.batch, 197, 768, 768, 3072
     T = B * N
     out = {"batch": B}
-    shapes = {"qkv": (T, 3 * I, D, 0), "out": (T, D, I, 2), "fc1": (T, M, D, 1), "fc2": (T, D, M, 2)}
+    shapes = {"qkv": (T, 3 * I, D, 0), "out": (T, D, I, 0), "fc1": (T, M, D, 1), "fc2": (T, D, M, 0)}
     g = torch.Generator(device="cuda").manual_seed(0)
     for name, (m, n, k, epi) in shapes.items():
         x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
