@@ -30,6 +30,8 @@ struct GemmBf16Params {
   int c_rgrp;                   // > 0: physical C row = m + m / c_rgrp + 1 (patch rows -> token rows)
   bf16_t* C2; int ldc2;         // BEPI_GELU2_BF16: pre-activation copy
   const bf16_t* aux; int ldaux; // BEPI_DGELU_BF16
+  int ksplit, kchunk;           // ksplit > 1: K is cut into ksplit slices of kchunk (multiple of 32); slice z writes C + z * slab_stride
+  long long slab_stride;        //             (BEPI_F32_PLAIN only; the slabs are summed by reduce_slabs)
 };
 
 int gemm_bf16(int epi, const GemmBf16Params& p, hipStream_t st);
@@ -43,6 +45,12 @@ int layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, bf
 int add_layernorm_fwd_bf16(const float* x, const bf16_t* delta, float* xout, const float* gamma, const float* beta, bf16_t* y,
                            float* mean, float* rstd, int T, int D, float eps, int rs, hipStream_t st);
 int residual_add_bf16(const float* x, const bf16_t* delta, float* xout, int rows, int D, int rs, hipStream_t st);
+int layernorm_bwd_bf16(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                       float* dx, bf16_t* dxb, float* dgamma, float* dbeta, float* partial, int T, int D, int rs, hipStream_t st);
+int transpose_bf16(const bf16_t* src, long long ld, bf16_t* dst, int rows, int cols, int ldd, hipStream_t st);
+int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int rows, int cols, hipStream_t st);
+int rowsum_bf16(const bf16_t* src, long long ld, float* out, int rows, int cols, hipStream_t st);
+int cast_bf16_f32(const bf16_t* src, float* dst, long long n, hipStream_t st);
 int attention_fwd_bf16(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N, int H, int dh, int nq, hipStream_t st);
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }

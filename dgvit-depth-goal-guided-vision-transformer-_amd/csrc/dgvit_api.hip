@@ -675,17 +675,20 @@ extern "C" int dgvit_gather_rows(const float* src, const long long* idx, float* 
 
 // ---------------------------------------------------------------------------------------------- bf16 configuration
 // BASELINE config 5 (224x224, ViT-Base variant, bf16): bf16 storage for GEMM operands (LayerNorm output, qkv,
-// attention output, MLP hidden, weights), fp32 residual stream / LayerNorm statistics / biases / softmax, fp32
-// accumulation on v_mfma_f32_32x32x16_bf16.  Same schedule as dgvit_got_forward (GoalFormer.py:156-171).
+// attention output, MLP hidden, branch outputs, weights, and in backward their gradients), fp32 residual stream and its
+// gradient / LayerNorm statistics / biases / softmax / parameter gradients, fp32 accumulation on
+// v_mfma_f32_32x32x16_bf16.  Same schedule as dgvit_got_forward / dgvit_got_backward (GoalFormer.py:156-171).
 #include "bf16.h"
 
 namespace {
 
 inline long long al128(long long bytes) { return (bytes + 255) & ~255ll; }
+inline int up8(long long n) { return (int)((n + 7) & ~7ll); }
 
-// bf16 weight arena (elements): patch weight, then per layer to_qkv, to_out, fc1, fc2 in the reference's (out, in) layouts
+// bf16 weight arena (elements): patch weight, then per layer to_qkv, to_out, fc1, fc2 in the reference's (out, in)
+// layouts, followed by their transposes (in, out) -- the B operands of the data-gradient GEMMs dX = dY W
 struct Wp {
-  long long patch, layer0, qkv, out, fc1, fc2, layer_elems, total;
+  long long patch, layer0, qkv, out, fc1, fc2, qkvT, outT, fc1T, fc2T, layer_elems, total;
 };
 Wp make_wp(const Dims& d) {
   Wp w;
@@ -696,16 +699,20 @@ Wp make_wp(const Dims& d) {
   w.out = l; l += (long long)d.D * d.I;
   w.fc1 = l; l += (long long)d.M * d.D;
   w.fc2 = l; l += (long long)d.D * d.M;
+  w.qkvT = l; l += (long long)3 * d.I * d.D;
+  w.outT = l; l += (long long)d.D * d.I;
+  w.fc1T = l; l += (long long)d.M * d.D;
+  w.fc2T = l; l += (long long)d.D * d.M;
   w.layer0 = o; w.layer_elems = al4(l);
   o += w.layer_elems * d.L;
   w.total = o;
   return w;
 }
 
-// activation workspace in BYTES
+// activation workspace in BYTES.  save: every layer keeps what backward needs; else the layers share one block.
 struct Wsb {
-  long long patches, xa, xb, pooled, layer0, layer_stride, total;
-  long long ln, qkv, ao, lse, xmid, a1, delta, layer_bytes;   // relative to the layer base
+  long long patches, xa, xb, pooled, delta, layer0, layer_stride, total;
+  long long ln, qkv, ao, lse, xmid, ln2, h1, a1, xout, mean1, rstd1, mean2, rstd2, layer_bytes;   // relative to the layer base
 };
 Wsb make_wsb(const Dims& d, int save) {
   Wsb w;
@@ -714,6 +721,7 @@ Wsb make_wsb(const Dims& d, int save) {
   w.xa = o; o += al128(d.T * d.D * 4);
   w.xb = o; o += al128(d.T * d.D * 4);
   w.pooled = o; o += al128((long long)d.B * d.D * 4);
+  w.delta = o; o += al128(d.T * d.D * 2);   // bf16 branch output (attention / feed-forward) before it joins the fp32 residual stream
   long long l = 0;
   w.ln = l; l += al128(d.T * d.D * 2);
   w.qkv = l; l += al128(d.T * 3 * d.I * 2);
@@ -721,7 +729,16 @@ Wsb make_wsb(const Dims& d, int save) {
   w.lse = l; l += al128((long long)d.B * d.H * d.N * 4);
   w.xmid = l; l += al128(d.T * d.D * 4);
   w.a1 = l; l += al128(d.T * d.M * 2);
-  w.delta = l; l += al128(d.T * d.D * 2);   // bf16 branch output (attention / feed-forward) before it joins the fp32 residual stream
+  w.ln2 = w.ln; w.h1 = w.xout = w.mean1 = w.rstd1 = w.mean2 = w.rstd2 = -1;
+  if (save) {
+    w.ln2 = l; l += al128(d.T * d.D * 2);
+    w.h1 = l; l += al128(d.T * d.M * 2);      // pre-GELU hidden (GELU' in backward)
+    w.xout = l; l += al128(d.T * d.D * 4);    // the layer's output = the next layer's residual input
+    w.mean1 = l; l += al128(d.T * 4);
+    w.rstd1 = l; l += al128(d.T * 4);
+    w.mean2 = l; l += al128(d.T * 4);
+    w.rstd2 = l; l += al128(d.T * 4);
+  }
   w.layer0 = o; w.layer_bytes = l;
   w.layer_stride = save ? l : 0;
   o += save ? l * d.L : l;
@@ -741,6 +758,81 @@ GemmBf16Params gpb(const bf16_t* A, int lda, const bf16_t* B, int ldb, void* C, 
   return p;
 }
 
+// split-K plan of a weight gradient dW (Mo x Ko) = sum over Tp token columns: about one virtual tile per CU
+struct SplitPlan { int splits, kchunk; long long slab; };
+SplitPlan wgrad_bf16_plan(int Mo, int Ko, int Tp) {
+  const long long tiles = (long long)((Mo + 255) / 256) * ((Ko + 255) / 256);
+  long long s = 256 / tiles;
+  if (s < 1) s = 1;
+  const long long maxs = (Tp + 511) / 512;   // at least 16 k-tiles per slice
+  if (s > maxs) s = maxs;
+  SplitPlan pl;
+  pl.kchunk = (int)((((Tp + s - 1) / s) + 31) / 32 * 32);
+  pl.splits = (Tp + pl.kchunk - 1) / pl.kchunk;
+  pl.slab = al4((long long)Mo * Ko);
+  return pl;
+}
+long long wgrad_bf16_scratch(int Mo, int Ko, int Tp) {
+  const SplitPlan pl = wgrad_bf16_plan(Mo, Ko, Tp);
+  return pl.splits > 1 ? pl.splits * pl.slab : 0;
+}
+// dW (Mo x Ko, fp32) = At (Mo x Tp) Bt (Ko x Tp)^T with the token dimension contiguous (transposed bf16 copies, zero padded to Tp)
+int wgrad_bf16(const bf16_t* At, const bf16_t* Bt, float* dW, int Mo, int Ko, int Tp, float* slabs, long long slab_floats,
+               hipStream_t st) {
+  const SplitPlan pl = wgrad_bf16_plan(Mo, Ko, Tp);
+  if (pl.splits == 1) {
+    GemmBf16Params p = gpb(At, Tp, Bt, Tp, dW, Ko, Mo, Ko, Tp);
+    return gemm_bf16(BEPI_F32_PLAIN, p, st);
+  }
+  if (slab_floats < pl.splits * pl.slab)
+    return dgvit_set_error(DGVIT_ERR_WORKSPACE, "wgrad_bf16: slabs %lld < %lld floats", slab_floats, pl.splits * pl.slab);
+  GemmBf16Params p = gpb(At, Tp, Bt, Tp, slabs, Ko, Mo, Ko, Tp);
+  p.ksplit = pl.splits; p.kchunk = pl.kchunk; p.slab_stride = pl.slab;
+  TRY(gemm_bf16(BEPI_F32_PLAIN, p, st));
+  return reduce_slabs(slabs, dW, (long long)Mo * Ko, pl.splits, pl.slab, st);
+}
+
+// backward scratch in BYTES
+struct Bsb {
+  long long dxa, dxb, dxh, dln, dqkv, dao, dh1, tA, tB, slabs, part, q32, ao32, dao32, dqkv32, patches32, total;
+  long long slab_floats;
+  int Tp;
+};
+Bsb make_bsb(const Dims& d) {
+  Bsb s;
+  s.Tp = up8(d.T);
+  long long o = 0;
+  s.dxa = o; o += al128(d.T * d.D * 4);
+  s.dxb = o; o += al128(d.T * d.D * 4);
+  s.dxh = o; o += al128(d.T * d.D * 2);
+  s.dln = o; o += al128(d.T * d.D * 2);
+  s.dqkv = o; o += al128(d.T * 3 * d.I * 2);
+  s.dao = o; o += al128(d.T * d.I * 2);
+  s.dh1 = o; o += al128(d.T * d.M * 2);
+  const long long widest = std::max<long long>(std::max(3 * d.I, d.M), d.D);
+  s.tA = o; o += al128(widest * s.Tp * 2);
+  s.tB = o; o += al128(widest * s.Tp * 2);
+  long long sl = wgrad_bf16_scratch(3 * d.I, d.D, s.Tp);
+  sl = std::max(sl, wgrad_bf16_scratch(d.D, d.I, s.Tp));
+  sl = std::max(sl, wgrad_bf16_scratch(d.M, d.D, s.Tp));
+  sl = std::max(sl, wgrad_bf16_scratch(d.D, d.M, s.Tp));
+  sl = std::max(sl, wgrad_scratch(d.D, d.pd, d.B * d.P));   // fp32 patch-embedding weight gradient
+  s.slab_floats = sl;
+  s.slabs = o; o += al128(sl * 4);
+  long long part = (long long)layernorm_bwd_blocks((int)d.T) * 2 * d.D;
+  part = std::max(part, (long long)colsum_blocks(d.B) * d.N * d.D);
+  part = std::max(part, (long long)rmsnorm_bwd_blocks(d.B) * d.D);
+  s.part = o; o += al128(part * 4);
+  // the attention core's backward runs on the fp32 kernels (attention.hip) over fp32 copies of its bf16 operands
+  s.q32 = o; o += al128(d.T * 3 * d.I * 4);
+  s.ao32 = o; o += al128(d.T * d.I * 4);
+  s.dao32 = o; o += al128(d.T * d.I * 4);
+  s.dqkv32 = o; o += al128(d.T * 3 * d.I * 4);
+  s.patches32 = o; o += al128((long long)d.B * d.P * d.pd * 4);
+  s.total = o;
+  return s;
+}
+
 }  // namespace
 
 extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = tile; }
@@ -755,8 +847,13 @@ extern "C" long long dgvit_got_bf16_weight_elems(const dgvit_config* cfg) {
 extern "C" long long dgvit_got_bf16_workspace_bytes(const dgvit_config* cfg, int batch, int save) {
   Dims d;
   if (make_dims(cfg, batch, d) || check_bf16_dims(d)) return -1;
-  DGVIT_CHECK_ARG(!save, "bf16 path: save_for_backward is not supported yet");
   return make_wsb(d, save).total;
+}
+
+extern "C" long long dgvit_got_bf16_backward_scratch_bytes(const dgvit_config* cfg, int batch) {
+  Dims d;
+  if (make_dims(cfg, batch, d) || check_bf16_dims(d)) return -1;
+  return make_bsb(d).total;
 }
 
 extern "C" int dgvit_got_pack_weights_bf16(const dgvit_config* cfg, const float* const* params, unsigned short* wpack,
@@ -776,6 +873,10 @@ extern "C" int dgvit_got_pack_weights_bf16(const dgvit_config* cfg, const float*
     TRY(cast_f32_bf16(lp[L_OUTW], lw + w.out, (long long)d.D * d.I, st));
     TRY(cast_f32_bf16(lp[L_FC1W], lw + w.fc1, (long long)d.M * d.D, st));
     TRY(cast_f32_bf16(lp[L_FC2W], lw + w.fc2, (long long)d.D * d.M, st));
+    TRY(transpose_cast_f32_bf16(lp[L_QKV], lw + w.qkvT, 3 * d.I, d.D, st));   // (3I, D) -> (D, 3I)
+    TRY(transpose_cast_f32_bf16(lp[L_OUTW], lw + w.outT, d.D, d.I, st));      // (D, I)  -> (I, D)
+    TRY(transpose_cast_f32_bf16(lp[L_FC1W], lw + w.fc1T, d.M, d.D, st));      // (M, D)  -> (D, M)
+    TRY(transpose_cast_f32_bf16(lp[L_FC2W], lw + w.fc2T, d.D, d.M, st));      // (D, M)  -> (M, D)
   }
   return DGVIT_OK;
 }
@@ -789,7 +890,6 @@ extern "C" int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* cons
   TRY(make_dims(cfg, batch, d));
   TRY(check_bf16_dims(d));
   DGVIT_CHECK_ARG(params && wpack && img && goal && feat && workspace, "dgvit_got_forward_bf16: null pointer");
-  DGVIT_CHECK_ARG(!save, "bf16 path: save_for_backward is not supported yet");
   DGVIT_CHECK_ARG(keep > 0.f && keep <= 1.f, "dropout_keep must be in (0, 1]");
   const Wsb w = make_wsb(d, save);
   const Wp wp = make_wp(d);
@@ -798,10 +898,11 @@ extern "C" int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* cons
   for (int i = 0; i < P_L0 + DGVIT_PARAMS_PER_LAYER * d.L; ++i) DGVIT_CHECK_ARG(params[i], "parameter %d is null", i);
   unsigned char* ws = (unsigned char*)workspace;
   const int T = (int)d.T;
+  auto f32 = [&](unsigned char* base, long long off) { return save ? (float*)(base + off) : (float*)nullptr; };
 
   bf16_t* patches = (bf16_t*)(ws + w.patches);
+  bf16_t* delta = (bf16_t*)(ws + w.delta);
   float* x = (float*)(ws + w.xa);
-  float* xnext = (float*)(ws + w.xb);
   TRY(patchify_bf16(img, patches, d.B, cfg->image_h, cfg->image_w, cfg->patch_h, cfg->patch_w, st));
   {
     GemmBf16Params p = gpb(patches, d.pd, wpack + wp.patch, d.pd, x, d.D, d.B * d.P, d.D, d.pd);
@@ -816,20 +917,25 @@ extern "C" int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* cons
   // The branch outputs (to_out, fc2: GoalFormer.py:82,49) are stored bf16 like every other GEMM output and join the fp32
   // residual stream inside the LayerNorm kernel of the next sub-block (x = attn(..) + x; x = ff(..) + x, :103-104): the GEMM
   // epilogues then have no fp32 residual read on their critical path.
-  TRY(layernorm_fwd_bf16(x, params[P_L0 + L_LN1W], params[P_L0 + L_LN1B], (bf16_t*)(ws + w.layer0 + w.ln), nullptr, nullptr, T, d.D,
-                         1e-5f, 1, st));
+  {
+    unsigned char* lb0 = ws + w.layer0;
+    TRY(layernorm_fwd_bf16(x, params[P_L0 + L_LN1W], params[P_L0 + L_LN1B], (bf16_t*)(lb0 + w.ln), f32(lb0, w.mean1), f32(lb0, w.rstd1),
+                           T, d.D, 1e-5f, 1, st));
+  }
   for (int i = 0; i < d.L; ++i) {
     const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
     const bf16_t* lw = wpack + wp.layer0 + wp.layer_elems * i;
     unsigned char* lb = ws + w.layer0 + w.layer_stride * i;
     bf16_t* ln = (bf16_t*)(lb + w.ln);
+    bf16_t* ln2 = (bf16_t*)(lb + w.ln2);
     bf16_t* qkv = (bf16_t*)(lb + w.qkv);
     bf16_t* ao = (bf16_t*)(lb + w.ao);
     float* xmid = (float*)(lb + w.xmid);
     bf16_t* a1 = (bf16_t*)(lb + w.a1);
-    bf16_t* delta = (bf16_t*)(lb + w.delta);
-    const bool last = g_prune_last && !d.pool_mean && i == d.L - 1;   // see dgvit_got_forward
+    // inference: the last block only needs token 0 downstream of K/V (see dgvit_got_forward); training keeps it dense
+    const bool last = g_prune_last && !save && !d.pool_mean && i == d.L - 1;
     const int tok = last ? d.B : T, rs = last ? d.N : 1;
+    float* xo = save ? (float*)(lb + w.xout) : (x == (float*)(ws + w.xa) ? (float*)(ws + w.xb) : (float*)(ws + w.xa));
     if (!last) {
       GemmBf16Params p = gpb(ln, d.D, lw + wp.qkv, d.D, qkv, 3 * d.I, T, 3 * d.I, d.D);
       TRY(gemm_bf16(BEPI_BF16, p, st));
@@ -839,33 +945,38 @@ extern "C" int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* cons
       GemmBf16Params q = gpb(ln, rs * d.D, lw + wp.qkv, d.D, qkv, rs * 3 * d.I, tok, d.I, d.D);
       TRY(gemm_bf16(BEPI_BF16, q, st));
     }
-    TRY(attention_fwd_bf16(qkv, ao, nullptr, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
+    TRY(attention_fwd_bf16(qkv, ao, f32(lb, w.lse), d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
     {
       GemmBf16Params p = gpb(ao, rs * d.I, lw + wp.out, d.I, delta, rs * d.D, tok, d.D, d.I);
       p.bias = lp[L_OUTB];
       TRY(gemm_bf16(BEPI_BF16, p, st));
     }
-    // xmid = x + to_out(..);  ln = LN2(xmid)
-    TRY(add_layernorm_fwd_bf16(x, delta, xmid, lp[L_LN2W], lp[L_LN2B], ln, nullptr, nullptr, tok, d.D, 1e-5f, rs, st));
+    // xmid = x + to_out(..);  ln2 = LN2(xmid)
+    TRY(add_layernorm_fwd_bf16(x, delta, xmid, lp[L_LN2W], lp[L_LN2B], ln2, f32(lb, w.mean2), f32(lb, w.rstd2), tok, d.D, 1e-5f, rs, st));
     {
-      GemmBf16Params p = gpb(ln, rs * d.D, lw + wp.fc1, d.D, a1, d.M, tok, d.M, d.D);
+      GemmBf16Params p = gpb(ln2, rs * d.D, lw + wp.fc1, d.D, a1, d.M, tok, d.M, d.D);
       p.bias = lp[L_FC1B];
-      TRY(gemm_bf16(BEPI_GELU_BF16, p, st));
+      if (save) {
+        p.C2 = (bf16_t*)(lb + w.h1); p.ldc2 = d.M;
+        TRY(gemm_bf16(BEPI_GELU2_BF16, p, st));
+      } else {
+        TRY(gemm_bf16(BEPI_GELU_BF16, p, st));
+      }
     }
     {
       GemmBf16Params p = gpb(a1, d.M, lw + wp.fc2, d.M, delta, rs * d.D, tok, d.D, d.M);
       p.bias = lp[L_FC2B];
       TRY(gemm_bf16(BEPI_BF16, p, st));
     }
-    // xnext = xmid + ff(..), and the next block's LN1 of it
+    // xo = xmid + ff(..), and the next block's LN1 of it
     if (i + 1 < d.L) {
       unsigned char* nb = ws + w.layer0 + w.layer_stride * (i + 1);
-      TRY(add_layernorm_fwd_bf16(xmid, delta, xnext, lp[DGVIT_PARAMS_PER_LAYER + L_LN1W], lp[DGVIT_PARAMS_PER_LAYER + L_LN1B],
-                                 (bf16_t*)(nb + w.ln), nullptr, nullptr, T, d.D, 1e-5f, 1, st));
+      TRY(add_layernorm_fwd_bf16(xmid, delta, xo, lp[DGVIT_PARAMS_PER_LAYER + L_LN1W], lp[DGVIT_PARAMS_PER_LAYER + L_LN1B],
+                                 (bf16_t*)(nb + w.ln), f32(nb, w.mean1), f32(nb, w.rstd1), T, d.D, 1e-5f, 1, st));
     } else {
-      TRY(residual_add_bf16(xmid, delta, xnext, tok, d.D, rs, st));
+      TRY(residual_add_bf16(xmid, delta, xo, tok, d.D, rs, st));
     }
-    std::swap(x, xnext);
+    x = xo;
   }
   if (d.pool_mean) {
     float* pooled = (float*)(ws + w.pooled);
@@ -873,6 +984,126 @@ extern "C" int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* cons
     return rmsnorm_fwd(pooled, d.D, params[P_RMS], feat, d.B, d.D, st);
   }
   return rmsnorm_fwd(x, (long long)d.N * d.D, params[P_RMS], feat, d.B, d.D, st);
+}
+
+// Gradient of dgvit_got_forward_bf16 (save_for_backward = 1).  Data-gradient GEMMs take the transposed weight copies of
+// the arena as B operand; weight-gradient GEMMs contract over tokens, so both operands are first transposed to
+// token-contiguous bf16 copies (zero padded to a multiple of 8 tokens) and the product is split over tokens into fp32
+// slabs that a fixed-order reduction sums (deterministic).  Bias gradients are the row sums of the transposed dY.
+extern "C" int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* const* params, const unsigned short* wpack,
+                                       float* const* grads, const float* dfeat, float* dgoal, const float* img,
+                                       const void* workspace, long long ws_bytes, void* scratch, long long scratch_bytes, int batch,
+                                       float keep, unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  Dims d;
+  TRY(make_dims(cfg, batch, d));
+  TRY(check_bf16_dims(d));
+  DGVIT_CHECK_ARG(params && wpack && grads && dfeat && img && workspace && scratch, "dgvit_got_backward_bf16: null pointer");
+  const Wsb w = make_wsb(d, 1);
+  const Wp wp = make_wp(d);
+  const Bsb s = make_bsb(d);
+  if (ws_bytes < w.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "bf16 backward workspace %lld < %lld bytes", ws_bytes, w.total);
+  if (scratch_bytes < s.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "bf16 backward scratch %lld < %lld bytes", scratch_bytes, s.total);
+  DGVIT_CHECK_ARG((uintptr_t)workspace % 256 == 0 && (uintptr_t)scratch % 256 == 0, "bf16 path: workspace / scratch must be 256-byte aligned");
+  const int np = P_L0 + DGVIT_PARAMS_PER_LAYER * d.L;
+  for (int i = 0; i < np; ++i) DGVIT_CHECK_ARG(params[i] && grads[i], "parameter/gradient %d is null", i);
+  const unsigned char* ws = (const unsigned char*)workspace;
+  unsigned char* sc = (unsigned char*)scratch;
+  const int T = (int)d.T, Tp = s.Tp;
+  float* dx = (float*)(sc + s.dxa);      // gradient of the residual stream entering the current op (fp32)
+  float* dx2 = (float*)(sc + s.dxb);
+  bf16_t* dxh = (bf16_t*)(sc + s.dxh);   // its bf16 copy: A operand of the data-gradient GEMMs, source of the transposed dY
+  bf16_t* dln = (bf16_t*)(sc + s.dln);
+  bf16_t* dqkv = (bf16_t*)(sc + s.dqkv);
+  bf16_t* dao = (bf16_t*)(sc + s.dao);
+  bf16_t* dh1 = (bf16_t*)(sc + s.dh1);
+  bf16_t* tA = (bf16_t*)(sc + s.tA);
+  bf16_t* tB = (bf16_t*)(sc + s.tB);
+  float* slabs = (float*)(sc + s.slabs);
+  float* part = (float*)(sc + s.part);
+
+  // dW (no x ni) and optionally db (no) from dY (T x no, row stride ldy) and X (T x ni, row stride ldx)
+  auto wgrad = [&](const bf16_t* dY, int ldy, const bf16_t* X, int ldx, float* dW, float* db, int no, int ni) -> int {
+    TRY(transpose_bf16(dY, ldy, tA, T, no, Tp, st));
+    TRY(transpose_bf16(X, ldx, tB, T, ni, Tp, st));
+    if (db) TRY(rowsum_bf16(tA, Tp, db, no, Tp, st));
+    return wgrad_bf16(tA, tB, dW, no, ni, Tp, slabs, s.slab_floats, st);
+  };
+
+  // RMSNorm on token 0 (or the token mean) of the last layer's output
+  const float* xl = (const float*)(ws + w.layer0 + w.layer_stride * (d.L - 1) + w.xout);
+  if (d.pool_mean) {
+    TRY(rmsnorm_bwd(dfeat, (const float*)(ws + w.pooled), d.D, params[P_RMS], dx2, d.D, grads[P_RMS], part, d.B, d.D, st));
+    TRY(mean_bwd(dx2, dx, d.B, d.N, d.D, st));
+  } else {
+    HIP_TRY(hipMemsetAsync(dx, 0, sizeof(float) * d.T * d.D, st));
+    TRY(rmsnorm_bwd(dfeat, xl, (long long)d.N * d.D, params[P_RMS], dx, (long long)d.N * d.D, grads[P_RMS], part, d.B, d.D, st));
+  }
+  TRY(cast_f32_bf16(dx, dxh, d.T * d.D, st));
+
+  for (int i = d.L - 1; i >= 0; --i) {
+    const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
+    float* const* lg = grads + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
+    const bf16_t* lw = wpack + wp.layer0 + wp.layer_elems * i;
+    const unsigned char* lb = ws + w.layer0 + w.layer_stride * i;
+    const float* xin = i == 0 ? (const float*)(ws + w.xa) : (const float*)(ws + w.layer0 + w.layer_stride * (i - 1) + w.xout);
+    const bf16_t* ln1 = (const bf16_t*)(lb + w.ln);
+    const bf16_t* ln2 = (const bf16_t*)(lb + w.ln2);
+    const bf16_t* qkv = (const bf16_t*)(lb + w.qkv);
+    const bf16_t* ao = (const bf16_t*)(lb + w.ao);
+    const bf16_t* h1 = (const bf16_t*)(lb + w.h1);
+    const bf16_t* a1 = (const bf16_t*)(lb + w.a1);
+    const float* xmid = (const float*)(lb + w.xmid);
+    // ---- feed-forward branch: xout = xmid + fc2(gelu(fc1(ln2)))        (dx / dxh = d xout)
+    TRY(wgrad(dxh, d.D, a1, d.M, lg[L_FC2W], lg[L_FC2B], d.D, d.M));
+    {
+      GemmBf16Params p = gpb(dxh, d.D, lw + wp.fc2T, d.D, dh1, d.M, T, d.M, d.D);   // dh1 = (dx W2) * gelu'(h1)
+      p.aux = h1; p.ldaux = d.M;
+      TRY(gemm_bf16(BEPI_DGELU_BF16, p, st));
+    }
+    TRY(wgrad(dh1, d.M, ln2, d.D, lg[L_FC1W], lg[L_FC1B], d.M, d.D));
+    {
+      GemmBf16Params p = gpb(dh1, d.M, lw + wp.fc1T, d.M, dln, d.D, T, d.D, d.M);     // dln2 = dh1 W1
+      TRY(gemm_bf16(BEPI_BF16, p, st));
+    }
+    TRY(layernorm_bwd_bf16(dln, xmid, (const float*)(lb + w.mean2), (const float*)(lb + w.rstd2), lp[L_LN2W], dx, dx2, dxh, lg[L_LN2W],
+                           lg[L_LN2B], part, T, d.D, 1, st));
+    // ---- attention branch: xmid = xin + to_out(attn(to_qkv(ln1)))      (dx2 / dxh = d xmid)
+    TRY(wgrad(dxh, d.D, ao, d.I, lg[L_OUTW], lg[L_OUTB], d.D, d.I));
+    {
+      GemmBf16Params p = gpb(dxh, d.D, lw + wp.outT, d.D, dao, d.I, T, d.I, d.D);     // dao = dxmid Wo
+      TRY(gemm_bf16(BEPI_BF16, p, st));
+    }
+    {
+      float* q32 = (float*)(sc + s.q32);
+      float* ao32 = (float*)(sc + s.ao32);
+      float* dao32 = (float*)(sc + s.dao32);
+      float* dqkv32 = (float*)(sc + s.dqkv32);
+      TRY(cast_bf16_f32(qkv, q32, d.T * 3 * d.I, st));
+      TRY(cast_bf16_f32(ao, ao32, d.T * d.I, st));
+      TRY(cast_bf16_f32(dao, dao32, d.T * d.I, st));
+      TRY(attention_bwd(q32, ao32, dao32, (const float*)(lb + w.lse), dqkv32, d.B, d.N, d.H, d.dh, d.N, st));
+      TRY(cast_f32_bf16(dqkv32, dqkv, d.T * 3 * d.I, st));
+    }
+    TRY(wgrad(dqkv, 3 * d.I, ln1, d.D, lg[L_QKV], nullptr, 3 * d.I, d.D));
+    {
+      GemmBf16Params p = gpb(dqkv, 3 * d.I, lw + wp.qkvT, 3 * d.I, dln, d.D, T, d.D, 3 * d.I);   // dln1 = dqkv Wqkv
+      TRY(gemm_bf16(BEPI_BF16, p, st));
+    }
+    TRY(layernorm_bwd_bf16(dln, xin, (const float*)(lb + w.mean1), (const float*)(lb + w.rstd1), lp[L_LN1W], dx2, dx, dxh, lg[L_LN1W],
+                           lg[L_LN1B], part, T, d.D, 1, st));
+  }
+  // ---- token assembly: x0 = dropout(cat(goal, patches W^T + b) + pos): fp32, as dgvit_got_backward
+  if (keep < 1.f) TRY(dropout_inplace(dx, d.T * d.D, seed, seed_dev, keep, st));
+  if (dgoal)
+    HIP_TRY(hipMemcpy2DAsync(dgoal, sizeof(float) * d.D, dx, sizeof(float) * d.N * d.D, sizeof(float) * d.D, d.B,
+                             hipMemcpyDeviceToDevice, st));
+  TRY(colsum(dx, (long long)d.N * d.D, grads[P_POS], part, d.B, d.N * d.D, 0, st));
+  HIP_TRY(hipMemcpy2DAsync(dx2, sizeof(float) * d.P * d.D, dx + d.D, sizeof(float) * d.N * d.D, sizeof(float) * d.P * d.D, d.B,
+                           hipMemcpyDeviceToDevice, st));
+  float* patches32 = (float*)(sc + s.patches32);
+  TRY(patchify(img, patches32, d.B, cfg->image_h, cfg->image_w, cfg->patch_h, cfg->patch_w, st));
+  return ::wgrad(dx2, d.D, patches32, d.pd, grads[P_PW], grads[P_PB], d.D, d.pd, d.B * d.P, slabs, s.slab_floats, st);
 }
 
 // operator-level exports of the bf16 kernels (parity tests, benches)
@@ -887,6 +1118,17 @@ extern "C" int dgvit_gemm_bf16(int epilogue, const unsigned short* A, int lda, c
   p.bias = bias; p.res = res; p.ldr = ldr; p.C2 = C2; p.ldc2 = ldc2; p.aux = aux; p.ldaux = ldaux;
   DGVIT_CHECK_ARG(epilogue != BEPI_DGELU_BF16 || aux, "dgvit_gemm_bf16: epilogue 3 needs aux");
   return gemm_bf16(epilogue, p, (hipStream_t)stream);
+}
+extern "C" long long dgvit_wgrad_bf16_scratch_floats(int Mo, int Ko, int T) { return wgrad_bf16_scratch(Mo, Ko, up8(T)); }
+extern "C" int dgvit_wgrad_bf16(const unsigned short* dY, const unsigned short* X, float* dW, float* db, unsigned short* tA,
+                                unsigned short* tB, float* slabs, long long slab_floats, int T, int Mo, int Ko, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DGVIT_CHECK_ARG(dY && X && dW && tA && tB && T > 0 && Mo > 0 && Ko > 0 && Mo % 8 == 0 && Ko % 8 == 0, "dgvit_wgrad_bf16: bad arguments");
+  const int Tp = up8(T);
+  TRY(transpose_bf16(dY, Mo, tA, T, Mo, Tp, st));
+  TRY(transpose_bf16(X, Ko, tB, T, Ko, Tp, st));
+  if (db) TRY(rowsum_bf16(tA, Tp, db, Mo, Tp, st));
+  return wgrad_bf16(tA, tB, dW, Mo, Ko, Tp, slabs, slab_floats, st);
 }
 extern "C" int dgvit_layernorm_forward_bf16(const float* x, const float* gamma, const float* beta, unsigned short* y, float* mean,
                                             float* rstd, int rows, int D, void* stream) {

@@ -236,7 +236,11 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   const int li = lane & 31, h = lane >> 5;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int wr = wave / T::WN, wc = wave % T::WN;
-  const int nkt = (p.K + 31) / 32;
+  // split-K (weight gradients: few output tiles, very long K): virtual tile v -> (output tile v / S, k-slice v % S);
+  // slice z covers k in [z * kchunk, min(K, (z + 1) * kchunk)) and writes its partial sums to slab z of C
+  const int S = p.ksplit > 1 ? p.ksplit : 1;
+  const int kchunk = S > 1 ? p.kchunk : ((p.K + 31) & ~31);
+  auto slice_len = [&](int z) { const int rem = p.K - z * kchunk; return rem < kchunk ? rem : kchunk; };
 
   // ---- load side: runs D k-tiles ahead of the compute side, across tile boundaries ---------------------------
   // one DMA instruction fills 16 rows x 64 bytes: lane -> row lane >> 2, physical chunk lane & 3, which holds logical
@@ -246,22 +250,24 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   const unsigned offA = ((unsigned)(wave * 16 + srow) * (unsigned)p.lda + sc * 8u) * 2u;
   const unsigned offB = ((unsigned)(wave * 16 + srow) * (unsigned)p.ldb + sc * 8u) * 2u;
   const unsigned stepA = 128u * (unsigned)p.lda * 2u, stepB = 128u * (unsigned)p.ldb * 2u;   // 8 waves x 16 rows
-  int ltile = blockIdx.x, lt = 0, lslot = 0;
+  int ltile = blockIdx.x, lt = 0, lslot = 0, lklen = 0, lnkt = 1;
   __amdgpu_buffer_rsrc_t rsA, rsB;
   auto set_load_tile = [&](int v) {
-    const int tile = xcd_chunk(v, ntiles);
+    const int vt = xcd_chunk(v, ntiles), tile = vt / S, k0 = (vt % S) * kchunk;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    long long abytes = ((long long)(p.M - 1 - m0) * p.lda + p.K) * 2, bbytes = ((long long)(p.N - 1 - n0) * p.ldb + p.K) * 2;
+    lklen = slice_len(vt % S);
+    lnkt = (lklen + 31) / 32;
+    long long abytes = ((long long)(p.M - 1 - m0) * p.lda + lklen) * 2, bbytes = ((long long)(p.N - 1 - n0) * p.ldb + lklen) * 2;
     if (abytes > 0x7FFFFFF0ll) abytes = 0x7FFFFFF0ll;
     if (bbytes > 0x7FFFFFF0ll) bbytes = 0x7FFFFFF0ll;
-    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + (long long)m0 * p.lda), 0, (int)abytes, 0x00020000);
-    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B + (long long)n0 * p.ldb), 0, (int)bbytes, 0x00020000);
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + (long long)m0 * p.lda + k0), 0, (int)abytes, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B + (long long)n0 * p.ldb + k0), 0, (int)bbytes, 0x00020000);
   };
   set_load_tile(ltile);   // blockIdx.x < ntiles by construction of the grid
   auto issue_next = [&]() {
     // past the last tile the same instructions still issue (every lane out of range, zeros into a free slot): the
     // vmcnt bookkeeping then is the same for every stream length
-    const unsigned dead = (ltile < ntiles && lt * 32 + sc * 8 < p.K) ? 0u : DGVIT_BUF_OOB;
+    const unsigned dead = (ltile < ntiles && lt * 32 + sc * 8 < lklen) ? 0u : DGVIT_BUF_OOB;
     const unsigned oa = (offA + (unsigned)lt * 64u) | dead, ob = (offB + (unsigned)lt * 64u) | dead;
     unsigned char* dst = smem + lslot * R::SLOT + wave * 1024;
 #pragma unroll
@@ -271,7 +277,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
     for (int i = 0; i < R::GB; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + BM * 64 + i * 8192), 16, ob + i * stepB, 0, 0, 0);
     lslot = lslot + 1 == NS ? 0 : lslot + 1;
-    if (++lt == nkt) {
+    if (++lt == lnkt) {
       lt = 0;
       ltile += gridDim.x;
       if (ltile < ntiles) set_load_tile(ltile);
@@ -290,6 +296,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   f32x16 acc[MT][NTL];
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int ctile = blockIdx.x, ct = 0, cslot = 0, since_epi = D, ntile_done = 0;
+  int cnkt = (slice_len(xcd_chunk(ctile, ntiles) % S) + 31) / 32;
   long long st0 = 0;
   if constexpr (STAMP) st0 = __builtin_amdgcn_s_memtime();
 
@@ -337,13 +344,13 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     cslot = cslot + 1 == NS ? 0 : cslot + 1;
-    if (++ct < nkt) continue;
+    if (++ct < cnkt) continue;
 
     // ---- epilogue of tile `ctile`: acc (column on the lane, rows in registers) -> wave-private LDS -> row pieces ----
     long long st1 = 0;
     if constexpr (STAMP) st1 = __builtin_amdgcn_s_memtime();
     {
-      const int tile = xcd_chunk(ctile, ntiles);
+      const int vt = xcd_chunk(ctile, ntiles), tile = vt / S;
       const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
       const int gn = n0 + wc * WTN + ecol;
       const bool ncol = gn < p.N;
@@ -351,7 +358,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
       const long long crow0 = p.c_rgrp > 0 ? m0 + m0 / p.c_rgrp + 1 : m0;
       constexpr int CES = (EPI == BEPI_F32 || EPI == BEPI_F32_PLAIN) ? 4 : 2;
       const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
-          reinterpret_cast<unsigned char*>(p.C) + (crow0 * p.ldc + n0) * CES, 0, (int)DGVIT_BUF_OOB, 0x00020000);
+          reinterpret_cast<unsigned char*>(p.C) + ((long long)(vt % S) * p.slab_stride + crow0 * p.ldc + n0) * CES, 0, (int)DGVIT_BUF_OOB,
+          0x00020000);
       __amdgpu_buffer_rsrc_t rsX = rsC;   // second operand of the epilogue: residual (fp32) / pre-activation copy / aux (bf16)
       if (EPI == BEPI_F32 && p.res)
         rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res) + ((long long)(p.res_mod > 0 ? 0 : m0) * p.ldr + n0), 0,
@@ -420,6 +428,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
     ct = 0;
     since_epi = 0;
     ctile += gridDim.x;
+    if (ctile < ntiles) cnkt = (slice_len(xcd_chunk(ctile, ntiles) % S) + 31) / 32;
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   wait_vmcnt<0>();   // the trailing (all-zero) LDS-DMAs must land before the workgroup gives its LDS back
@@ -454,21 +463,28 @@ int launch(const GemmBf16Params& p, hipStream_t st) {
         return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit to %d bytes", LDS);
       attr_done = true;
     }
-    const int grid = (int)(tiles < num_cus() ? tiles : num_cus());   // one persistent workgroup per CU
+    const int S = p.ksplit > 1 ? p.ksplit : 1;
+    DGVIT_CHECK_ARG(S == 1 || (p.kchunk > 0 && p.kchunk % 32 == 0 && (long long)(S - 1) * p.kchunk < p.K && (long long)S * p.kchunk >= p.K),
+                    "gemm_bf16: bad split-K plan (%d x %d over K=%d)", S, p.kchunk, p.K);
+    DGVIT_CHECK_ARG(S == 1 || EPI == BEPI_F32_PLAIN, "gemm_bf16: split-K needs the plain fp32 epilogue");
+    const long long vtiles = tiles * S;
+    DGVIT_CHECK_ARG(vtiles < (1ll << 30), "gemm_bf16: too many tiles");
+    const int grid = (int)(vtiles < num_cus() ? vtiles : num_cus());   // one persistent workgroup per CU
     if constexpr (EPI == BEPI_BF16) {
       if (g_gemm_bf16_stamps) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<T, EPI, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
           return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit");
-        hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI, true>), dim3(grid), dim3(512), LDS, st, p, (int)tiles, g_gemm_bf16_stamps);
+        hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI, true>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, g_gemm_bf16_stamps);
         DGVIT_CHECK_LAUNCH("gemm_bf16_ring_kernel(stamps)");
         return DGVIT_OK;
       }
     }
     const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, st);
-    hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI>), dim3(grid), dim3(512), LDS, st, p, (int)tiles, (long long*)nullptr);
+    hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, (long long*)nullptr);
     profile_end(slot, st);
   } else {
+    DGVIT_CHECK_ARG(p.ksplit <= 1, "gemm_bf16: split-K needs a 256-row tile");
     if (!attr_done) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               T::LDS) != hipSuccess)
@@ -489,7 +505,7 @@ int dispatch(const GemmBf16Params& p, hipStream_t st) {
   int tile = g_gemm_bf16_tile_hint;
   if (!tile) {
     const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    tile = (p.M >= 256 && p.N >= 256 && t256 >= 512) ? 256256 : 128128;
+    tile = (p.ksplit > 1 || (p.M >= 256 && p.N >= 256 && t256 >= 512)) ? 256256 : 128128;
   }
   switch (tile) {
     case 256256: return launch<BTile<256, 256, 2, 4>, EPI, true>(p, st);

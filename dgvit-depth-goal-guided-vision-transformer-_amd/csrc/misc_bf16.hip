@@ -152,3 +152,114 @@ int add_layernorm_fwd_bf16(const float* x, const bf16_t* delta, float* xout, con
   DGVIT_CHECK_ARG(delta && xout, "add_layernorm_bf16: bad arguments");
   return layernorm_launch<true>(x, delta, xout, gamma, beta, y, mean, rstd, T, D, eps, rs, st);
 }
+
+// ---------------------------------------------------------------------------------------------- backward helpers
+namespace {
+
+// dst (cols x ldd) = src (rows x cols, row stride ld)^T on 64 x 64 tiles through LDS; dst columns [rows, ldd) are zero
+// filled (ldd = rows rounded up to 8: the token dimension of the weight-gradient operands).  SRC = bf16_t or float
+// (the fp32 -> bf16 cast of a weight fused with its transposition).  cols % 8 == 0.
+typedef bf16_t u16x8 __attribute__((ext_vector_type(8)));
+
+template <typename SRC>
+__global__ void __launch_bounds__(256) transpose_bf16_kernel(const SRC* __restrict__ src, long long ld, bf16_t* __restrict__ dst,
+                                                             int rows, int cols, int ldd) {
+  __shared__ bf16_t tile[64][66];   // 66: a column walk advances 33 dwords per row -> conflict-free 16-bit column reads
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + i * 256, r = f >> 3, c8 = (f & 7) * 8;
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r0 + r < rows && c0 + c8 < cols) {
+      if constexpr (sizeof(SRC) == 2) {
+        v = *reinterpret_cast<const u16x8*>(src + (long long)(r0 + r) * ld + c0 + c8);
+      } else {
+        const fx4 a = *reinterpret_cast<const fx4*>(src + (long long)(r0 + r) * ld + c0 + c8);
+        const fx4 b = *reinterpret_cast<const fx4*>(src + (long long)(r0 + r) * ld + c0 + c8 + 4);
+        const bf16x4 a4 = __builtin_convertvector(a, bf16x4), b4 = __builtin_convertvector(b, bf16x4);
+        // (whole-vector shuffle + bit cast: element-wise writes into the 16-bit vector were miscompiled by hipcc 7.2,
+        //  only elements 0 and 4 survived)
+        v = __builtin_bit_cast(u16x8, __builtin_shufflevector(a4, b4, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[r][c8 + j] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + i * 256, c = f >> 3, r8 = (f & 7) * 8;   // output row c0 + c, output columns r0 + r8 .. + 7
+    if (c0 + c < cols && r0 + r8 < ldd) {
+      u16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = tile[r8 + j][c];   // rows >= `rows` were staged as zeros
+      *reinterpret_cast<u16x8*>(dst + (long long)(c0 + c) * ldd + r0 + r8) = o;
+    }
+  }
+}
+
+// out[r] = sum_c src[r][c] (fp32 accumulation, fixed order): bias gradients from the transposed dY copies
+__global__ void __launch_bounds__(256) rowsum_bf16_kernel(const bf16_t* __restrict__ src, long long ld, float* __restrict__ out, int cols) {
+  __shared__ float red[4];
+  const bf16_t* row = src + (long long)blockIdx.x * ld;
+  float s = 0.f;
+  for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
+    if (c + 8 <= cols) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[j];
+    } else {
+      for (int j = c; j < cols; ++j) s += bf16_to_f32(row[j]);
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+__global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long long n4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  reinterpret_cast<fx4*>(dst)[i] = __builtin_convertvector(reinterpret_cast<const bf16x4*>(src)[i], fx4);
+}
+
+}  // namespace
+
+int transpose_bf16(const bf16_t* src, long long ld, bf16_t* dst, int rows, int cols, int ldd, hipStream_t st) {
+  DGVIT_CHECK_ARG(src && dst && rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0, "transpose_bf16: cols and ld must be multiples of 8");
+  DGVIT_CHECK_ARG(ldd >= rows && ldd % 8 == 0 && ldd - rows < 8, "transpose_bf16: ldd must be rows rounded up to a multiple of 8");
+  const int slot = profile_begin(PROF_OTHER, 0.0, st);
+  hipLaunchKernelGGL((transpose_bf16_kernel<bf16_t>), dim3((cols + 63) / 64, (ldd + 63) / 64), dim3(256), 0, st, src, ld, dst, rows, cols,
+                     ldd);
+  profile_end(slot, st);
+  DGVIT_CHECK_LAUNCH("transpose_bf16");
+  return DGVIT_OK;
+}
+
+int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int rows, int cols, hipStream_t st) {
+  DGVIT_CHECK_ARG(src && dst && rows > 0 && cols > 0 && cols % 8 == 0 && rows % 8 == 0,
+                  "transpose_cast_f32_bf16: rows and cols must be multiples of 8");
+  hipLaunchKernelGGL((transpose_bf16_kernel<float>), dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, src, (long long)cols, dst,
+                     rows, cols, rows);
+  DGVIT_CHECK_LAUNCH("transpose_cast_f32_bf16");
+  return DGVIT_OK;
+}
+
+int rowsum_bf16(const bf16_t* src, long long ld, float* out, int rows, int cols, hipStream_t st) {
+  DGVIT_CHECK_ARG(src && out && rows > 0 && cols > 0 && ld % 8 == 0, "rowsum_bf16: bad arguments");
+  const int slot = profile_begin(PROF_OTHER, 0.0, st);
+  hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(rows), dim3(256), 0, st, src, ld, out, cols);
+  profile_end(slot, st);
+  DGVIT_CHECK_LAUNCH("rowsum_bf16");
+  return DGVIT_OK;
+}
+
+int cast_bf16_f32(const bf16_t* src, float* dst, long long n, hipStream_t st) {
+  DGVIT_CHECK_ARG(src && dst && n > 0 && n % 4 == 0, "cast_bf16_f32: n must be a positive multiple of 4");
+  const long long n4 = n / 4;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, src, dst, n4);
+  DGVIT_CHECK_LAUNCH("cast_bf16_f32");
+  return DGVIT_OK;
+}

@@ -6,8 +6,15 @@
 // partial row into a slab, reduce_slabs() adds the slabs in a fixed order.
 #include "common.h"
 #include "kernels.h"
+#include "bf16.h"
 
 namespace {
+
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const bf16_t* p) {
+  const fx4 v = __builtin_convertvector(*reinterpret_cast<const bf16x4*>(p), fx4);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
 
 // ---------------------------------------------------------------- LayerNorm forward
 __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -52,12 +59,14 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const float* __restr
 // ---------------------------------------------------------------- LayerNorm backward
 // dx[t] = dres[t] + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 // partial[blk][0][c] = sum_rows dy * xhat (dgamma),  partial[blk][1][c] = sum_rows dy (dbeta)
-template <int NCH>
-__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// DYT = float (fp32 path) or bf16_t (bf16 configuration: dy is a bf16 GEMM output; dxb, if given, receives a bf16 copy of
+// dx -- the operand of the next data- and weight-gradient GEMMs)
+template <int NCH, typename DYT>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const DYT* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ dres,
-                                                            float* __restrict__ dx, float* __restrict__ partial, int T, int D,
-                                                            int rs) {
+                                                            float* __restrict__ dx, bf16_t* __restrict__ dxb,
+                                                            float* __restrict__ partial, int T, int D, int rs) {
   __shared__ float red[4][2][NCH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 ag[NCH], ab[NCH], gm[NCH];
@@ -80,7 +89,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
       g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       xh[i] = g[i];
       if (c < D) {
-        const float4 d = *reinterpret_cast<const float4*>(dy + off + c);
+        const float4 d = load4(dy + off + c);
         const float4 v = *reinterpret_cast<const float4*>(x + off + c);
         xh[i] = make_float4((v.x - mu) * rsd, (v.y - mu) * rsd, (v.z - mu) * rsd, (v.w - mu) * rsd);
         ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
@@ -105,6 +114,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const float* __restr
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
         *reinterpret_cast<float4*>(dx + off + c) = o;
+        if (dxb) *reinterpret_cast<bf16x4*>(dxb + off + c) = __builtin_convertvector(fx4{o.x, o.y, o.z, o.w}, bf16x4);
       }
     }
   }
@@ -214,7 +224,8 @@ int layernorm_bwd(const float* dy, const float* x, const float* mean, const floa
   const int nb = layernorm_bwd_blocks(T);
   const int nch = (D + 255) / 256;
 #define LNB(NCH)                                                                                                              \
-  hipLaunchKernelGGL(layernorm_bwd_kernel<NCH>, dim3(nb), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dres, dx, partial, T, D, rs)
+  hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, float>), dim3(nb), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dres, dx, \
+                     (bf16_t*)nullptr, partial, T, D, rs)
   if (nch == 1) LNB(1);
   else if (nch == 2) LNB(2);
   else if (nch == 3) LNB(3);
@@ -222,6 +233,27 @@ int layernorm_bwd(const float* dy, const float* x, const float* mean, const floa
 #undef LNB
   DGVIT_CHECK_LAUNCH("layernorm_bwd");
   // partial is [nb][2][D]: one pass reduces both halves (stride 2*D), first D sums -> dgamma, next D -> dbeta
+  return reduce_slabs2(partial, dgamma, D, dbeta, 2ll * D, nb, 2ll * D, stream);
+}
+
+// bf16 configuration: dy bf16; dx fp32 (+ optional bf16 copy dxb)
+int layernorm_bwd_bf16(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                       float* dx, bf16_t* dxb, float* dgamma, float* dbeta, float* partial, int T, int D, int rs, hipStream_t stream) {
+  DGVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && partial, "layernorm_bwd_bf16: null pointer");
+  DGVIT_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bwd_bf16: D=%d must be a multiple of 4, <= 1024", D);
+  const int nb = layernorm_bwd_blocks(T);
+  const int nch = (D + 255) / 256;
+  const int slot = profile_begin(PROF_OTHER, 0.0, stream);
+#define LNB(NCH)                                                                                                              \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, bf16_t>), dim3(nb), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dres, dx, dxb, \
+                     partial, T, D, rs)
+  if (nch == 1) LNB(1);
+  else if (nch == 2) LNB(2);
+  else if (nch == 3) LNB(3);
+  else LNB(4);
+#undef LNB
+  profile_end(slot, stream);
+  DGVIT_CHECK_LAUNCH("layernorm_bwd_bf16");
   return reduce_slabs2(partial, dgamma, D, dbeta, 2ll * D, nb, 2ll * D, stream);
 }
 

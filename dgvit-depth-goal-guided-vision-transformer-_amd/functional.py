@@ -388,27 +388,87 @@ class Bf16Weights:
         return self.arena
 
 
-def got_encoder_bf16(img, goal, cfg_tuple, params, weights: Bf16Weights, dropout_keep=1.0, dropout_seed=0):
-    """GoT.forward in the bf16 configuration (inference: no autograd graph is recorded)."""
+def op_wgrad_bf16(dy, x, want_bias=True):
+    """dW (Mo, Ko) fp32 = dY^T X, db = column sums of dY, for bf16 dY (T, Mo), X (T, Ko)."""
     lib = _lib.load()
-    cfg = dgvit_config(*cfg_tuple)
-    img, goal = _dev(img, "img"), _dev(goal, "goal")
-    params = [_dev(p.detach(), f"param[{i}]") for i, p in enumerate(params)]
-    if img.dim() != 3 or img.shape[1] != cfg.image_h or img.shape[2] != cfg.image_w:
-        raise DgvitError(f"img must be (B, {cfg.image_h}, {cfg.image_w}), got {tuple(img.shape)}")
-    B = img.shape[0]
-    if goal.shape != (B, cfg.dim):
-        raise DgvitError(f"goal must be ({B}, {cfg.dim}), got {tuple(goal.shape)}")
-    wpack = weights.get(cfg, params)
-    nws = lib.dgvit_got_bf16_workspace_bytes(ctypes.byref(cfg), B, 0)
-    if nws < 0:
-        _lib.check(-1, "dgvit_got_bf16_workspace_bytes")
-    ws = torch.empty(nws, dtype=torch.uint8, device=img.device)
-    feat = torch.empty(B, cfg.dim, dtype=torch.float32, device=img.device)
-    seed_dev = dropout_seed if isinstance(dropout_seed, torch.Tensor) else None
-    seed_val = 0 if seed_dev is not None else int(dropout_seed)
-    with torch.cuda.device(img.device):
-        rc = lib.dgvit_got_forward_bf16(ctypes.byref(cfg), _table(params), _ptr(wpack), _ptr(img), _ptr(goal), _ptr(feat), _ptr(ws),
-                                        nws, B, 0, float(dropout_keep), seed_val, _ptr(seed_dev), _stream())
-    _lib.check(rc, "dgvit_got_forward_bf16")
-    return feat
+    dy, x = _dev_bf16(dy, "dy"), _dev_bf16(x, "x")
+    T, Mo = dy.shape
+    Ko = x.shape[1]
+    T8 = (T + 7) // 8 * 8
+    dev = dy.device
+    dw = torch.empty(Mo, Ko, dtype=torch.float32, device=dev)
+    db = torch.empty(Mo, dtype=torch.float32, device=dev) if want_bias else None
+    ta = torch.empty(Mo * T8, dtype=torch.bfloat16, device=dev)
+    tb = torch.empty(Ko * T8, dtype=torch.bfloat16, device=dev)
+    ns = lib.dgvit_wgrad_bf16_scratch_floats(Mo, Ko, T)
+    slabs = torch.empty(max(ns, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.dgvit_wgrad_bf16(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(ta), _ptr(tb), _ptr(slabs), ns, T, Mo, Ko, _stream())
+    _lib.check(rc, "dgvit_wgrad_bf16")
+    return (dw, db) if want_bias else dw
+
+
+class _GoTEncoderBf16(torch.autograd.Function):
+    """GoT.forward in the bf16 configuration as one autograd node (dgvit_got_forward_bf16 / dgvit_got_backward_bf16)."""
+
+    @staticmethod
+    def forward(ctx, img, goal, cfg_tuple, keep, seed, need_grad, weights, *params):
+        lib = _lib.load()
+        cfg = dgvit_config(*cfg_tuple)
+        img, goal = _dev(img, "img"), _dev(goal, "goal")
+        params = [_dev(p, f"param[{i}]") for i, p in enumerate(params)]
+        nparam = _lib.NUM_GLOBAL_PARAMS + _lib.PARAMS_PER_LAYER * cfg.depth
+        if len(params) != nparam:
+            raise DgvitError(f"expected {nparam} parameter tensors, got {len(params)}")
+        if img.dim() != 3 or img.shape[1] != cfg.image_h or img.shape[2] != cfg.image_w:
+            raise DgvitError(f"img must be (B, {cfg.image_h}, {cfg.image_w}), got {tuple(img.shape)}")
+        B = img.shape[0]
+        if goal.shape != (B, cfg.dim):
+            raise DgvitError(f"goal must be ({B}, {cfg.dim}), got {tuple(goal.shape)}")
+        wpack = weights.get(cfg, params)
+        nws = lib.dgvit_got_bf16_workspace_bytes(ctypes.byref(cfg), B, int(need_grad))
+        if nws < 0:
+            _lib.check(-1, "dgvit_got_bf16_workspace_bytes")
+        ws = torch.empty(nws, dtype=torch.uint8, device=img.device)
+        feat = torch.empty(B, cfg.dim, dtype=torch.float32, device=img.device)
+        seed_dev = seed if isinstance(seed, torch.Tensor) else None
+        seed_val = 0 if seed_dev is not None else int(seed)
+        with torch.cuda.device(img.device):
+            rc = lib.dgvit_got_forward_bf16(ctypes.byref(cfg), _table(params), _ptr(wpack), _ptr(img), _ptr(goal), _ptr(feat), _ptr(ws),
+                                            nws, B, int(need_grad), float(keep), seed_val, _ptr(seed_dev), _stream())
+        _lib.check(rc, "dgvit_got_forward_bf16")
+        if need_grad:
+            ctx.cfg_tuple, ctx.keep, ctx.seed, ctx.batch = cfg_tuple, float(keep), seed_val, B
+            ctx.seed_dev, ctx.ws, ctx.wpack, ctx.img = seed_dev, ws, wpack, img
+            ctx.save_for_backward(*params)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        lib = _lib.load()
+        cfg = dgvit_config(*ctx.cfg_tuple)
+        params = list(ctx.saved_tensors)
+        dfeat = _dev(dfeat, "dfeat")
+        B, dev = ctx.batch, dfeat.device
+        sizes = [p.numel() for p in params]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + ((n + 3) & ~3))
+        flat = torch.empty(offs[-1], dtype=torch.float32, device=dev)     # one flat gradient buffer (see _GoTEncoder.backward)
+        grads = [flat[o:o + n].view_as(p) for o, n, p in zip(offs, sizes, params)]
+        dgoal = torch.empty(B, cfg.dim, dtype=torch.float32, device=dev)
+        nsc = lib.dgvit_got_bf16_backward_scratch_bytes(ctypes.byref(cfg), B)
+        scratch = torch.empty(nsc, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.dgvit_got_backward_bf16(ctypes.byref(cfg), _table(params), _ptr(ctx.wpack), _table(grads), _ptr(dfeat), _ptr(dgoal),
+                                             _ptr(ctx.img), _ptr(ctx.ws), ctx.ws.numel(), _ptr(scratch), nsc, B, ctx.keep, ctx.seed,
+                                             _ptr(ctx.seed_dev), _stream())
+        _lib.check(rc, "dgvit_got_backward_bf16")
+        ctx.ws = ctx.wpack = ctx.img = None
+        return (None, dgoal, None, None, None, None, None, *grads)
+
+
+def got_encoder_bf16(img, goal, cfg_tuple, params, weights: Bf16Weights, dropout_keep=1.0, dropout_seed=0):
+    """GoT.forward in the bf16 configuration (bf16 storage of GEMM operands, fp32 master parameters and gradients)."""
+    need_grad = torch.is_grad_enabled() and (goal.requires_grad or any(p.requires_grad for p in params))
+    return _GoTEncoderBf16.apply(img, goal, tuple(cfg_tuple), dropout_keep, dropout_seed, need_grad, weights, *params)

@@ -138,7 +138,5 @@ class GoT(nn.Module):
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())   # CPU generator: follows torch.manual_seed, no device sync
         params = self.param_table()
         if self.compute_dtype == torch.bfloat16:
-            if torch.is_grad_enabled() and (goal.requires_grad or any(p.requires_grad for p in params)):
-                raise NotImplementedError("the bf16 configuration has no backward yet: call it under torch.no_grad()")
             return F_.got_encoder_bf16(img, goal, self._cfg, params, self._bf16_weights, keep, seed)
         return F_.got_encoder(img, goal, self._cfg, params, keep, seed)

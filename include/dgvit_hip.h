@@ -204,7 +204,7 @@ int dgvit_soft_update(float* target, const float* source, long long n, float tau
  * stream, LayerNorm statistics, biases, softmax, accumulation on v_mfma_f32_32x32x16_bf16, RMSNorm, output).
  * bf16 values are raw 16-bit patterns (unsigned short).  Needs dim_head 64 and dim, mlp_dim, patch pixels % 8 == 0.
  *   wpack: bf16 copies of the GEMM weights in one arena of dgvit_got_bf16_weight_elems elements
- *          [patch weight | per layer: to_qkv, to_out, fc1, fc2], refreshed with dgvit_got_pack_weights_bf16 whenever the
+ *          [patch weight | per layer: to_qkv, to_out, fc1, fc2 and their transposes], refreshed with dgvit_got_pack_weights_bf16 whenever the
  *          fp32 master parameters change; `params` is the fp32 table of dgvit_got_forward (biases, norms, pos_embedding).
  *   workspace: dgvit_got_bf16_workspace_bytes BYTES, 256-byte aligned.
  * -------------------------------------------------------------------------------------------- */
@@ -216,7 +216,24 @@ int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* const* params, 
                            const float* goal, float* feat, void* workspace, long long workspace_bytes, int batch,
                            int save_for_backward, float dropout_keep, unsigned long long dropout_seed,
                            const unsigned long long* dropout_seed_dev, void* stream);
+/* Training in the bf16 configuration: forward with save_for_backward = 1 (dense last block), then
+ *   dfeat (B, D) -> grads[] (fp32, table order of params, each written), dgoal (B, D) (may be NULL).
+ * Gradients of GEMM operands travel bf16 (dY of every Linear), the residual-stream gradient, LayerNorm / bias / weight
+ * gradients are fp32; weight gradients are fp32 split-K slabs summed in a fixed order (deterministic).  The attention
+ * core's backward runs on the fp32 kernels of dgvit_attention_backward over fp32 copies of its bf16 operands.
+ * `img` is the forward's input (the patch-embedding weight gradient re-gathers the patches in fp32);
+ * scratch: dgvit_got_bf16_backward_scratch_bytes BYTES, 256-byte aligned. */
+long long dgvit_got_bf16_backward_scratch_bytes(const dgvit_config* cfg, int batch);
+int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* const* params, const unsigned short* wpack, float* const* grads,
+                            const float* dfeat, float* dgoal, const float* img, const void* workspace, long long workspace_bytes,
+                            void* scratch, long long scratch_bytes, int batch, float dropout_keep, unsigned long long dropout_seed,
+                            const unsigned long long* dropout_seed_dev, void* stream);
 /* operator-level entry points of the bf16 kernels (parity tests, benches) */
+/* dW (Mo, Ko) fp32 = dY^T X and db (Mo, may be NULL) = column sums of dY, for dY (T, Mo) and X (T, Ko) bf16 (Mo, Ko % 8 == 0):
+ * both are transposed into tA (Mo x T8) / tB (Ko x T8), T8 = T rounded up to 8, then multiplied split over tokens. */
+long long dgvit_wgrad_bf16_scratch_floats(int Mo, int Ko, int T);
+int dgvit_wgrad_bf16(const unsigned short* dY, const unsigned short* X, float* dW, float* db, unsigned short* tA, unsigned short* tB,
+                     float* slabs, long long slab_floats, int T, int Mo, int Ko, void* stream);
 int dgvit_cast_f32_bf16(const float* src, unsigned short* dst, long long n, void* stream);
 /* C = A B^T (+ epilogue), A (M,K) / B (N,K) bf16 with k contiguous, K, lda, ldb % 8 == 0, N, ldc % 4 == 0.
  * epilogue 0: C bf16 = acc + bias;  1: C bf16 = gelu(acc + bias);  2: C fp32 = acc + bias + res (fp32);

@@ -190,14 +190,102 @@ def test_encoder_bf16_vs_reference_and_oracle(name):
     assert (feat - dense).abs().max() < 2e-2
 
 
-def test_encoder_bf16_needs_no_grad_and_gpu():
+def test_encoder_bf16_dtype_switch():
     import dgvit_amd
     m = dgvit_amd.GoT(image_size=(32, 32), patch_size=(8, 8), num_classes=2, dim=64, depth=1, heads=2, mlp_dim=64, channels=1)
-    m = m.cuda().set_compute_dtype(torch.bfloat16)
-    with pytest.raises(NotImplementedError):
-        m(torch.rand(2, 32, 32).cuda(), torch.rand(2, 64).cuda())
     with pytest.raises(ValueError):
         m.set_compute_dtype(torch.float16)
+    m = m.cuda().eval()
+    img, goal = torch.rand(2, 32, 32).cuda(), torch.rand(2, 64).cuda()
+    with torch.no_grad():
+        f32 = m(img, goal)
+        fbf = m.set_compute_dtype(torch.bfloat16)(img, goal)
+        back = m.set_compute_dtype(torch.float32)(img, goal)
+    assert torch.equal(f32, back)
+    assert 0 < float((f32 - fbf).abs().max()) < 3e-2
+
+
+# ---------------------------------------------------------------------------------------------- backward
+@pytest.mark.parametrize("T,Mo,Ko", [(394, 136, 264), (4000, 768, 2304), (9001, 256, 256), (64, 8, 8), (20000, 3072, 768)])
+def test_wgrad_bf16(F, T, Mo, Ko):
+    """dW = dY^T X through the token-contiguous transposes and the split-K GEMM; db = column sums"""
+    dy, x = rb(rnd(T, Mo, seed=1)), rb(rnd(T, Ko, seed=2))
+    dw, db = F.op_wgrad_bf16(dbf(dy), dbf(x))
+    close(dw, dy.T @ x, atol=3e-5 * T ** 0.5 + 1e-6 * T, msg="dW")
+    close(db, dy.sum(0), atol=3e-5 * T ** 0.5 + 1e-6 * T, msg="db")
+
+
+def _grad_case(cfg, batch, seed, pool="cls"):
+    import dgvit_amd
+    params = O.make_params(O.got_param_spec(cfg, prefix=""), seed)
+    img, _, _, _ = O.make_inputs(cfg, batch, seed)
+    rs = np.random.RandomState(seed + 7)
+    goal = torch.from_numpy(rs.standard_normal((batch, cfg.dim))).float()
+    wout = torch.from_numpy(rs.standard_normal((batch, cfg.dim))).float()
+    # references on the CPU: fp32 restatement and the bf16-storage model (its casts also round the gradients to bf16)
+    refs = {}
+    for name, fn in (("fp32", O.got_forward), ("bf16 model", O.got_forward_bf16)):
+        ps = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        g = goal.clone().requires_grad_(True)
+        (fn(ps, img, g, cfg, prefix="", pool=pool) * wout).sum().backward()
+        refs[name] = ({k: v.grad for k, v in ps.items()}, g.grad)
+    m = dgvit_amd.GoT(image_size=cfg.image, patch_size=cfg.patch, num_classes=2, dim=cfg.dim, depth=cfg.depth, heads=cfg.heads,
+                      mlp_dim=cfg.mlp_dim, dim_head=cfg.dim_head, channels=1, pool=pool)
+    m.load_state_dict(params, strict=True)
+    m = m.cuda().eval().set_compute_dtype(torch.bfloat16)
+    gd = goal.cuda().requires_grad_(True)
+    feat = m(img.cuda(), gd)
+    (feat * wout.cuda()).sum().backward()
+    ours = {k: (None if v.grad is None else v.grad.cpu()) for k, v in m.named_parameters()}
+    return ours, gd.grad.cpu(), refs
+
+
+@pytest.mark.parametrize("case", ["small84", "c5_l2", "odd", "meanpool"])
+def test_encoder_bf16_gradients(case):
+    cfg, batch, pool = {
+        "small84": (O.GoTConfig(image=(84, 84), patch=(12, 12), dim=256, depth=3, heads=8, dim_head=64, mlp_dim=2048), 8, "cls"),
+        "c5_l2": (O.GoTConfig(image=(224, 224), patch=(16, 16), dim=768, depth=2, heads=12, dim_head=64, mlp_dim=3072), 3, "cls"),
+        "odd": (O.GoTConfig(image=(40, 56), patch=(8, 8), dim=72, depth=2, heads=3, dim_head=64, mlp_dim=200), 5, "cls"),
+        "meanpool": (O.GoTConfig(image=(48, 48), patch=(12, 12), dim=128, depth=2, heads=2, dim_head=64, mlp_dim=256), 6, "mean"),
+    }[case]
+    ours, dgoal, refs = _grad_case(cfg, batch, 21, pool)
+    worst = {}
+    for name, (gref, dgoal_ref) in refs.items():
+        errs = {}
+        for k, g in gref.items():
+            if g is None or float(g.abs().max()) == 0.0:
+                assert ours[k] is None or float(ours[k].abs().max()) == 0.0, f"{k} should have no gradient"
+                continue
+            assert ours[k] is not None, f"{k}: no gradient"
+            errs[k] = float((ours[k] - g).norm() / g.norm())
+        errs["dgoal"] = float((dgoal - dgoal_ref).norm() / dgoal_ref.norm())
+        worst[name] = max(errs.items(), key=lambda kv: kv[1])
+        bad = {k: round(v, 4) for k, v in errs.items() if v > 2e-2}
+        if bad:
+            print(f"{case} vs {name}: tensors beyond tolerance: {bad}")
+    print(f"{case}: worst relative gradient error vs fp32 {worst['fp32']}, vs bf16 model {worst['bf16 model']}")
+    # relative L2 error per parameter tensor: bf16 storage of activations AND of the gradients flowing between GEMMs
+    assert worst["fp32"][1] < 2e-2
+    assert worst["bf16 model"][1] < 2e-2
+
+
+def test_encoder_bf16_training_step_reduces_loss():
+    """a few Adam steps on the bf16 configuration (fp32 master weights, bf16 copies re-packed after every step)"""
+    import dgvit_amd
+    from dgvit_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    m = dgvit_amd.GoT(image_size=(84, 84), patch_size=(12, 12), num_classes=2, dim=256, depth=2, heads=4, mlp_dim=512, channels=1)
+    m = m.cuda().train().set_compute_dtype(torch.bfloat16)
+    opt = FlatAdam([m], lr=1e-3)
+    img, goal, tgt = torch.rand(32, 84, 84).cuda(), torch.randn(32, 256).cuda(), torch.randn(32, 256).cuda()
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        loss = ((m(img, goal) - tgt) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
 def test_encoder_bf16_full_size_properties():

@@ -71,6 +71,31 @@ def main():
         flops = 34.972e9 * B
         out["forward_c5"] = {"ms": round(ms, 3), "frames_per_s": round(B / ms * 1e3, 1), "tflops_dense": round(flops / ms / 1e9, 1)}
         print("forward_c5", out["forward_c5"], flush=True)
+    if not a.no_forward:
+        # forward + backward (training mode: dense last block, activations kept), no optimizer step
+        m.train()
+        tgt = torch.randn(B, 768, device="cuda", generator=g)
+
+        def fb():
+            for p_ in m.parameters():
+                p_.grad = None
+            loss = ((m(img, goal) - tgt) ** 2).mean()
+            loss.backward()
+
+        import ctypes
+        from dgvit_amd import _lib
+        ms = timeit(fb, iters=5, warm=2)
+        lib.dgvit_profile_start(8192)
+        fb()
+        torch.cuda.synchronize()
+        kinds = _lib.PROFILE_KINDS
+        pm, pw, pc = (ctypes.c_double * kinds)(), (ctypes.c_double * kinds)(), (ctypes.c_longlong * kinds)()
+        lib.dgvit_profile_stop(pm, pw, pc)
+        out["fwd_bwd_c5"] = {"ms": round(ms, 3), "frames_per_s": round(B / ms * 1e3, 1), "tflops_dense": round(3 * 34.972e9 * B / ms / 1e9, 1),
+                             "gemm_ms": round(pm[0], 3), "gemm_tflops": round(pw[0] / max(pm[0], 1e-9) / 1e9, 1), "attn_fwd_ms": round(pm[1], 3),
+                             "attn_bwd_ms": round(pm[2], 3), "other_profiled_ms": round(pm[3], 3),
+                             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}
+        print("fwd_bwd_c5", out["fwd_bwd_c5"], flush=True)
     print(json.dumps(out))
 
 
