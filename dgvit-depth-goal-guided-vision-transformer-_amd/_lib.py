@@ -77,6 +77,7 @@ SIGNATURES = {
     "dgvit_set_gemm_bf16_stamps": (None, [_P]),
     "dgvit_layernorm_forward_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dgvit_attention_forward_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dgvit_attention_backward_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dgvit_profile_start": (_I, [_I]),
     "dgvit_profile_stop": (_I, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_longlong)]),
 }

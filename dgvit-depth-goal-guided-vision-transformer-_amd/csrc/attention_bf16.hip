@@ -146,6 +146,218 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_bf16_kernel(const bf16_t* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward
+// Two kernels, each one workgroup of 8 waves per (frame, head), probabilities recomputed from the saved base-2
+// log-sum-exp (nothing of size N x N is stored):
+//   dq kernel (wave = 32-query tile; K, V row images and K transposed in LDS):
+//     P^T = exp2(K Q^T sc - lse), dP^T = V dO^T, delta = rowsum(dO o O), dS^T = P^T o (dP^T - delta) * scale,
+//     dQ^T += K^T dS^T          (delta is also written out for the second kernel)
+//   dkv kernel (wave = 32-key tile; Q, dO row images and both transposed in LDS):
+//     P = exp2(Q K^T sc - lse), dP = dO V^T, dS = P o (dP - delta) * scale, dV^T += dO^T P, dK^T += Q^T dS
+// Every product keeps the "accumulator registers are the next MFMA's B operand" orientation of the forward kernel.
+
+// rows [0, N) of a 64-wide per-head column block -> LDS row image [NP][128 B], chunks swizzled by ((row >> 1) & 7)
+template <int NTHR>
+__device__ __forceinline__ void stage_rows(unsigned char* img, const bf16_t* src, long long ld, int N, int NP, int tid) {
+  for (int f = tid; f < NP * 8; f += NTHR) {
+    const int row = f >> 3, pc = f & 7, c = pc ^ ((row >> 1) & 7);
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (row < N) v = *reinterpret_cast<const u32x4_t*>(src + row * ld + c * 8);
+    *reinterpret_cast<u32x4_t*>(img + row * 128 + pc * 16) = v;
+  }
+}
+// the same block transposed: img[d][vt_pos(row)], row stride VS elements (see the header of this file)
+template <int NTHR>
+__device__ __forceinline__ void stage_transposed(bf16_t* img, const bf16_t* src, long long ld, int N, int NP, int VS, int tid) {
+  for (int f = tid; f < (NP / 2) * 8; f += NTHR) {
+    const int kp = f >> 3, dc = f & 7, row = kp * 2;
+    u32x4_t v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
+    if (row < N) v0 = *reinterpret_cast<const u32x4_t*>(src + row * ld + dc * 8);
+    if (row + 1 < N) v1 = *reinterpret_cast<const u32x4_t*>(src + (row + 1) * ld + dc * 8);
+    unsigned* dst = reinterpret_cast<unsigned*>(img + (dc * 8) * VS + vt_pos(row));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dst[(2 * i) * (VS / 2)] = (v0[i] & 0xFFFFu) | (v1[i] << 16);
+      dst[(2 * i + 1) * (VS / 2)] = (v0[i] >> 16) | (v1[i] & 0xFFFF0000u);
+    }
+  }
+}
+
+// acc += rows(img, tile base row `row0`) . frags   (A = 32 image rows x 64 deep, B = per-lane fragments)
+__device__ __forceinline__ void mfma_rows(f32x16& acc, const unsigned char* img, int row0, int li, int h, const bf16x8 (&fb)[4]) {
+  const unsigned fsw = (unsigned)((li >> 1) & 7);
+  const unsigned char* rp = img + (row0 + li) * 128;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(rp + (((2 * s + h) ^ fsw) * 16));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, fb[s], acc, 0, 0, 0);
+  }
+}
+// acc[dt] += transposed(img)[d tile dt][32 contraction rows from `pos0`] . bf16(x)   (x = 32x32 fp32 tile, rows contracted)
+__device__ __forceinline__ void mfma_transposed(f32x16 (&acc)[2], const bf16_t* img, int VS, int pos0, int li, int h, const f32x16& x) {
+  bf16x8 xf[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xf[s][j] = (__bf16)x[8 * s + j];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(img + (dt * 32 + li) * VS + pos0 + 16 * s + 8 * h);
+      acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[s], acc[dt], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void load_frags(bf16x8 (&f)[4], const bf16_t* rowptr, int h) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) f[s] = *reinterpret_cast<const bf16x8*>(rowptr + 16 * s + 8 * h);
+}
+// transposed accumulator pair (rows = d, token on the lane) -> bf16 row `rowptr` (64 wide)
+__device__ __forceinline__ void store_T_bf16(const f32x16 (&o)[2], bf16_t* rowptr, int h, float mul) {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      fx4 v = {o[dt][4 * c] * mul, o[dt][4 * c + 1] * mul, o[dt][4 * c + 2] * mul, o[dt][4 * c + 3] * mul};
+      *reinterpret_cast<bf16x4*>(rowptr + dt * 32 + 8 * c + 4 * h) = __builtin_convertvector(v, bf16x4);
+    }
+}
+
+__global__ void __launch_bounds__(512) attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o_fwd,
+                                                               const bf16_t* __restrict__ d_out, const float* __restrict__ lse,
+                                                               bf16_t* __restrict__ dqkv, float* __restrict__ delta, int N, int H,
+                                                               float scale) {
+  constexpr int DH = 64, NTHR = 512, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nkt = (N + 31) / 32, NP = nkt * 32, VS = NP + 8;
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + NP * 128;
+  bf16_t* Kt = reinterpret_cast<bf16_t*>(smem + 2 * NP * 128);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x / H, hd = blockIdx.x % H;
+  const int I = H * DH;
+  const long long ld = 3ll * I;
+  const bf16_t* base = qkv + (long long)b * N * ld + hd * DH;
+  const float sc = scale * DGVIT_LOG2E;
+  stage_rows<NTHR>(Ks, base + I, ld, N, NP, tid);
+  stage_rows<NTHR>(Vs, base + 2 * I, ld, N, NP, tid);
+  stage_transposed<NTHR>(Kt, base + I, ld, N, NP, VS, tid);
+  __syncthreads();
+  for (int qt = wave; qt < nkt; qt += NW) {
+    const int q = qt * 32 + li, qc = q < N ? q : 0;
+    bf16x8 qf[4], dof[4], of[4];
+    load_frags(qf, base + qc * ld, h);
+    load_frags(dof, d_out + ((long long)b * N + qc) * I + hd * DH, h);
+    load_frags(of, o_fwd + ((long long)b * N + qc) * I + hd * DH, h);
+    float dl = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl += (float)dof[s][j] * (float)of[s][j];
+    dl += __shfl_xor(dl, 32, 64);
+    const float lq = lse[((long long)b * H + hd) * N + qc];
+    f32x16 dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dq[0][r] = 0.f;
+      dq[1][r] = 0.f;
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+      f32x16 s0, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = 0.f;
+        dp[r] = 0.f;
+      }
+      mfma_rows(s0, Ks, kt * 32, li, h, qf);
+      mfma_rows(dp, Vs, kt * 32, li, h, dof);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + acc_row(r, h);
+        const float pr = key < N ? __builtin_amdgcn_exp2f(s0[r] * sc - lq) : 0.f;
+        s0[r] = pr * (dp[r] - dl) * scale;   // dS^T
+      }
+      mfma_transposed(dq, Kt, VS, kt * 32, li, h, s0);
+    }
+    if (q < N) {
+      store_T_bf16(dq, dqkv + ((long long)b * N + q) * ld + hd * DH, h, 1.f);
+      if (h == 0) delta[((long long)b * H + hd) * N + q] = dl;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(512) attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_out,
+                                                                const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+  constexpr int DH = 64, NTHR = 512, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nkt = (N + 31) / 32, NP = nkt * 32, VS = NP + 8;
+  unsigned char* Qs = smem;
+  unsigned char* Os = smem + NP * 128;                                     // dO rows
+  bf16_t* Qt = reinterpret_cast<bf16_t*>(smem + 2 * NP * 128);
+  bf16_t* Ot = Qt + 64 * VS;                                               // dO transposed
+  float* lse_s = reinterpret_cast<float*>(Ot + 64 * VS);
+  float* del_s = lse_s + NP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x / H, hd = blockIdx.x % H;
+  const int I = H * DH;
+  const long long ld = 3ll * I;
+  const bf16_t* base = qkv + (long long)b * N * ld + hd * DH;
+  const bf16_t* dob = d_out + (long long)b * N * I + hd * DH;
+  const float sc = scale * DGVIT_LOG2E;
+  stage_rows<NTHR>(Qs, base, ld, N, NP, tid);
+  stage_rows<NTHR>(Os, dob, I, N, NP, tid);
+  stage_transposed<NTHR>(Qt, base, ld, N, NP, VS, tid);
+  stage_transposed<NTHR>(Ot, dob, I, N, NP, VS, tid);
+  for (int i = tid; i < NP; i += NTHR) {
+    lse_s[i] = i < N ? lse[((long long)b * H + hd) * N + i] : 0.f;
+    del_s[i] = i < N ? delta[((long long)b * H + hd) * N + i] : 0.f;
+  }
+  __syncthreads();
+  for (int kt = wave; kt < nkt; kt += NW) {
+    const int key = kt * 32 + li, kc = key < N ? key : 0;
+    const bool kvalid = key < N;
+    bf16x8 kf[4], vf[4];
+    load_frags(kf, base + I + kc * ld, h);
+    load_frags(vf, base + 2 * I + kc * ld, h);
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f;
+    }
+    for (int qt = 0; qt < nkt; ++qt) {
+      f32x16 s0, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = 0.f;
+        dp[r] = 0.f;
+      }
+      mfma_rows(s0, Qs, qt * 32, li, h, kf);     // S[query][key]: queries in the registers, key on the lane
+      mfma_rows(dp, Os, qt * 32, li, h, vf);     // dP = dO V^T
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int q0 = qt * 32 + 8 * g + 4 * h;  // registers 4g .. 4g+3 hold queries q0 .. q0+3
+        const fx4 l4 = *reinterpret_cast<const fx4*>(lse_s + q0), d4 = *reinterpret_cast<const fx4*>(del_s + q0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * g + i;
+          const float pr = (kvalid && q0 + i < N) ? __builtin_amdgcn_exp2f(s0[r] * sc - l4[i]) : 0.f;
+          s0[r] = pr;                                // P
+          dp[r] = pr * (dp[r] - d4[i]) * scale;      // dS
+        }
+      }
+      mfma_transposed(dv, Ot, VS, qt * 32, li, h, s0);   // dV^T += dO^T P
+      mfma_transposed(dk, Qt, VS, qt * 32, li, h, dp);   // dK^T += Q^T dS
+    }
+    if (kvalid) {
+      store_T_bf16(dk, dqkv + ((long long)b * N + key) * ld + I + hd * DH, h, 1.f);
+      store_T_bf16(dv, dqkv + ((long long)b * N + key) * ld + 2 * I + hd * DH, h, 1.f);
+    }
+  }
+}
+
 }  // namespace
 
 int attention_fwd_bf16(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N, int H, int dh, int nq, hipStream_t st) {
@@ -161,5 +373,35 @@ int attention_fwd_bf16(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N,
   hipLaunchKernelGGL((attn_fwd_bf16_kernel<4>), dim3((unsigned)((long long)B * H)), dim3(256), lds, st, qkv, out, lse, N, H, scale, nq);
   profile_end(slot, st);
   DGVIT_CHECK_LAUNCH("attn_fwd_bf16_kernel");
+  return DGVIT_OK;
+}
+
+// dqkv (B, N, 3I) bf16 = gradient of the attention core; delta: B*H*N floats of scratch
+int attention_bwd_bf16(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, float* delta, int B,
+                       int N, int H, int dh, hipStream_t st) {
+  DGVIT_CHECK_ARG(qkv && out && dout && lse && dqkv && delta && B > 0 && H > 0, "attention_bwd_bf16: bad arguments");
+  DGVIT_CHECK_ARG(dh == 64, "attention_bwd_bf16: dim_head=%d unsupported (64)", dh);
+  DGVIT_CHECK_ARG(N >= 1 && N <= 224, "attention_bwd_bf16: tokens N=%d outside [1, 224]", N);
+  const int NP = (N + 31) / 32 * 32;
+  const size_t lds_q = (size_t)2 * NP * 128 + (size_t)64 * (NP + 8) * 2;
+  const size_t lds_kv = (size_t)2 * NP * 128 + (size_t)2 * 64 * (NP + 8) * 2 + (size_t)2 * NP * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) !=
+            hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return dgvit_set_error(DGVIT_ERR_HIP, "attention_bwd_bf16: cannot raise the dynamic LDS limit");
+    attr_done = true;
+  }
+  const float scale = 1.0f / sqrtf((float)dh);
+  const double flops = 10.0 * (double)N * N * dh * H * B;   // 2.5 x forward
+  const int slot = profile_begin(PROF_ATTN_BWD, flops, st);
+  hipLaunchKernelGGL(attn_bwd_dq_bf16_kernel, dim3((unsigned)((long long)B * H)), dim3(512), lds_q, st, qkv, out, dout, lse, dqkv, delta, N,
+                     H, scale);
+  hipLaunchKernelGGL(attn_bwd_dkv_bf16_kernel, dim3((unsigned)((long long)B * H)), dim3(512), lds_kv, st, qkv, dout, lse, delta, dqkv, N, H,
+                     scale);
+  profile_end(slot, st);
+  DGVIT_CHECK_LAUNCH("attention_bwd_bf16");
   return DGVIT_OK;
 }

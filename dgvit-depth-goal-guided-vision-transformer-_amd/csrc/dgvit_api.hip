@@ -794,7 +794,7 @@ int wgrad_bf16(const bf16_t* At, const bf16_t* Bt, float* dW, int Mo, int Ko, in
 
 // backward scratch in BYTES
 struct Bsb {
-  long long dxa, dxb, dxh, dln, dqkv, dao, dh1, tA, tB, slabs, part, q32, ao32, dao32, dqkv32, patches32, total;
+  long long dxa, dxb, dxh, dln, dqkv, dao, dh1, tA, tB, slabs, part, delta, patches32, total;
   long long slab_floats;
   int Tp;
 };
@@ -823,11 +823,7 @@ Bsb make_bsb(const Dims& d) {
   part = std::max(part, (long long)colsum_blocks(d.B) * d.N * d.D);
   part = std::max(part, (long long)rmsnorm_bwd_blocks(d.B) * d.D);
   s.part = o; o += al128(part * 4);
-  // the attention core's backward runs on the fp32 kernels (attention.hip) over fp32 copies of its bf16 operands
-  s.q32 = o; o += al128(d.T * 3 * d.I * 4);
-  s.ao32 = o; o += al128(d.T * d.I * 4);
-  s.dao32 = o; o += al128(d.T * d.I * 4);
-  s.dqkv32 = o; o += al128(d.T * 3 * d.I * 4);
+  s.delta = o; o += al128((long long)d.B * d.H * d.N * 4);   // rowsum(dO o O) of the attention backward
   s.patches32 = o; o += al128((long long)d.B * d.P * d.pd * 4);
   s.total = o;
   return s;
@@ -1074,17 +1070,7 @@ extern "C" int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* con
       GemmBf16Params p = gpb(dxh, d.D, lw + wp.outT, d.D, dao, d.I, T, d.I, d.D);     // dao = dxmid Wo
       TRY(gemm_bf16(BEPI_BF16, p, st));
     }
-    {
-      float* q32 = (float*)(sc + s.q32);
-      float* ao32 = (float*)(sc + s.ao32);
-      float* dao32 = (float*)(sc + s.dao32);
-      float* dqkv32 = (float*)(sc + s.dqkv32);
-      TRY(cast_bf16_f32(qkv, q32, d.T * 3 * d.I, st));
-      TRY(cast_bf16_f32(ao, ao32, d.T * d.I, st));
-      TRY(cast_bf16_f32(dao, dao32, d.T * d.I, st));
-      TRY(attention_bwd(q32, ao32, dao32, (const float*)(lb + w.lse), dqkv32, d.B, d.N, d.H, d.dh, d.N, st));
-      TRY(cast_f32_bf16(dqkv32, dqkv, d.T * 3 * d.I, st));
-    }
+    TRY(attention_bwd_bf16(qkv, ao, dao, (const float*)(lb + w.lse), dqkv, (float*)(sc + s.delta), d.B, d.N, d.H, d.dh, st));
     TRY(wgrad(dqkv, 3 * d.I, ln1, d.D, lg[L_QKV], nullptr, 3 * d.I, d.D));
     {
       GemmBf16Params p = gpb(dqkv, 3 * d.I, lw + wp.qkvT, 3 * d.I, dln, d.D, T, d.D, 3 * d.I);   // dln1 = dqkv Wqkv
@@ -1133,6 +1119,11 @@ extern "C" int dgvit_wgrad_bf16(const unsigned short* dY, const unsigned short* 
 extern "C" int dgvit_layernorm_forward_bf16(const float* x, const float* gamma, const float* beta, unsigned short* y, float* mean,
                                             float* rstd, int rows, int D, void* stream) {
   return layernorm_fwd_bf16(x, gamma, beta, y, mean, rstd, rows, D, 1e-5f, 1, (hipStream_t)stream);
+}
+extern "C" int dgvit_attention_backward_bf16(const unsigned short* qkv, const unsigned short* out, const unsigned short* dout,
+                                             const float* lse, unsigned short* dqkv, float* delta, int B, int N, int H, int dh,
+                                             void* stream) {
+  return attention_bwd_bf16(qkv, out, dout, lse, dqkv, delta, B, N, H, dh, (hipStream_t)stream);
 }
 extern "C" int dgvit_attention_forward_bf16(const unsigned short* qkv, unsigned short* out, float* lse, int B, int N, int H, int dh,
                                             void* stream) {

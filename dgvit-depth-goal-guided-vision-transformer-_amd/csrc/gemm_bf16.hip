@@ -372,10 +372,25 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
       fx4 bias4 = {0.f, 0.f, 0.f, 0.f};
       if (p.bias && ncol) bias4 = *reinterpret_cast<const fx4*>(p.bias + gn);
       const unsigned coln = (unsigned)(wc * WTN + ecol);
+      // GELU' epilogue: the pre-activation loads of 32-row group i + 1 are issued before group i is processed (the
+      // fragment registers are free now), so their latency -- they queue behind the LDS-DMAs already in flight -- is
+      // paid about once per tile, not once per store
+      constexpr int NQ = 16 / RPI;
+      u32x2v auxv[EPI == BEPI_DGELU_BF16 ? MT : 1][2 * NQ];
+      auto aux_fetch = [&](int i, u32x2v (&dst)[2 * NQ]) {
+#pragma unroll
+        for (int hq = 0; hq < 2 * NQ; ++hq) {
+          const int ml = wr * WTM + i * 32 + (hq / NQ) * 16 + (hq % NQ) * RPI + erow;
+          const unsigned xoff = (m0 + ml < p.M && ncol) ? ((unsigned)ml * (unsigned)p.ldaux + coln) * 2u : DGVIT_BUF_OOB;
+          dst[hq] = __builtin_amdgcn_raw_buffer_load_b64(rsX, xoff, 0, 0);
+        }
+      };
+      if (EPI == BEPI_DGELU_BF16) aux_fetch(0, auxv[0]);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+          if (EPI == BEPI_DGELU_BF16 && half == 0 && i + 1 < MT) aux_fetch(i + 1, auxv[EPI == BEPI_DGELU_BF16 ? i + 1 : 0]);
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int j = 0; j < NTL; ++j)
@@ -408,8 +423,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
               fx4 g = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
               __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(g, bf16x4)), rsC, coff, 0, 0);
             } else {  // BEPI_DGELU_BF16
-              const unsigned xoff = ok ? ((unsigned)ml * (unsigned)p.ldaux + coln) * 2u : DGVIT_BUF_OOB;
-              const bf16x4 a = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rsX, xoff, 0, 0));
+              const bf16x4 a = __builtin_bit_cast(bf16x4, auxv[EPI == BEPI_DGELU_BF16 ? i : 0][half * NQ + q]);
               fx4 g = {v[0] * gelu_erf_grad((float)a[0]), v[1] * gelu_erf_grad((float)a[1]), v[2] * gelu_erf_grad((float)a[2]),
                        v[3] * gelu_erf_grad((float)a[3])};
               __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(g, bf16x4)), rsC, coff, 0, 0);

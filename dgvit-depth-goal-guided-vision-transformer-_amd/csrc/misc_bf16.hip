@@ -160,41 +160,54 @@ namespace {
 // filled (ldd = rows rounded up to 8: the token dimension of the weight-gradient operands).  SRC = bf16_t or float
 // (the fp32 -> bf16 cast of a weight fused with its transposition).  cols % 8 == 0.
 typedef bf16_t u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4m __attribute__((ext_vector_type(4)));
+
+// dst (cols x ldd) = src (rows x cols, row stride ld)^T on 64 x 64 tiles; dst columns [rows, ldd) are zero filled
+// (ldd = rows rounded up to 8: the token dimension of the weight-gradient operands).  SRC = bf16_t or float (the
+// fp32 -> bf16 cast of a weight fused with its transposition).  cols % 8 == 0.
+// A thread loads 8 columns of TWO adjacent rows and interleaves them in registers into 8 dwords {row r, row r + 1} of one
+// column each -- already transposed pairs -- so the LDS tile T[col][row pair] is written with dword stores (stride 33:
+// at most 2-way bank conflicts) and read back for the output rows with one ds_read_b128 per 16-byte store.
+template <typename SRC>
+__device__ __forceinline__ u32x4m load8(const SRC* p) {
+  if constexpr (sizeof(SRC) == 2) {
+    return *reinterpret_cast<const u32x4m*>(p);
+  } else {
+    const fx4 a = *reinterpret_cast<const fx4*>(p), b = *reinterpret_cast<const fx4*>(p + 4);
+    const bf16x4 a4 = __builtin_convertvector(a, bf16x4), b4 = __builtin_convertvector(b, bf16x4);
+    // (whole-vector shuffle + bit cast: element-wise writes into a 16-bit vector were miscompiled by hipcc 7.2)
+    return __builtin_bit_cast(u32x4m, __builtin_shufflevector(a4, b4, 0, 1, 2, 3, 4, 5, 6, 7));
+  }
+}
 
 template <typename SRC>
 __global__ void __launch_bounds__(256) transpose_bf16_kernel(const SRC* __restrict__ src, long long ld, bf16_t* __restrict__ dst,
                                                              int rows, int cols, int ldd) {
-  __shared__ bf16_t tile[64][66];   // 66: a column walk advances 33 dwords per row -> conflict-free 16-bit column reads
+  __shared__ unsigned tile[64][33];   // [column][row pair]
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int f = tid + i * 256, r = f >> 3, c8 = (f & 7) * 8;
-    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (r0 + r < rows && c0 + c8 < cols) {
-      if constexpr (sizeof(SRC) == 2) {
-        v = *reinterpret_cast<const u16x8*>(src + (long long)(r0 + r) * ld + c0 + c8);
-      } else {
-        const fx4 a = *reinterpret_cast<const fx4*>(src + (long long)(r0 + r) * ld + c0 + c8);
-        const fx4 b = *reinterpret_cast<const fx4*>(src + (long long)(r0 + r) * ld + c0 + c8 + 4);
-        const bf16x4 a4 = __builtin_convertvector(a, bf16x4), b4 = __builtin_convertvector(b, bf16x4);
-        // (whole-vector shuffle + bit cast: element-wise writes into the 16-bit vector were miscompiled by hipcc 7.2,
-        //  only elements 0 and 4 survived)
-        v = __builtin_bit_cast(u16x8, __builtin_shufflevector(a4, b4, 0, 1, 2, 3, 4, 5, 6, 7));
-      }
+  {
+    const int rp = tid >> 3, c8 = (tid & 7) * 8, r = r0 + 2 * rp;   // 32 row pairs x 8 column chunks
+    u32x4m lo = {0u, 0u, 0u, 0u}, hi = {0u, 0u, 0u, 0u};
+    if (c0 + c8 < cols) {
+      if (r < rows) lo = load8(src + (long long)r * ld + c0 + c8);
+      if (r + 1 < rows) hi = load8(src + (long long)(r + 1) * ld + c0 + c8);
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) tile[r][c8 + j] = v[j];
+    for (int i = 0; i < 4; ++i) {
+      tile[c8 + 2 * i][rp] = (lo[i] & 0xFFFFu) | (hi[i] << 16);
+      tile[c8 + 2 * i + 1][rp] = (lo[i] >> 16) | (hi[i] & 0xFFFF0000u);
+    }
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int f = tid + i * 256, c = f >> 3, r8 = (f & 7) * 8;   // output row c0 + c, output columns r0 + r8 .. + 7
     if (c0 + c < cols && r0 + r8 < ldd) {
-      u16x8 o;
+      u32x4m o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = tile[r8 + j][c];   // rows >= `rows` were staged as zeros
-      *reinterpret_cast<u16x8*>(dst + (long long)(c0 + c) * ldd + r0 + r8) = o;
+      for (int j = 0; j < 4; ++j) o[j] = tile[c][(r8 >> 1) + j];   // rows >= `rows` were staged as zeros
+      *reinterpret_cast<u32x4m*>(dst + (long long)(c0 + c) * ldd + r0 + r8) = o;
     }
   }
 }

@@ -364,6 +364,19 @@ def op_attention_bf16(qkv, heads, dim_head=64, want_lse=False):
     return (out, lse) if want_lse else out
 
 
+def op_attention_bwd_bf16(qkv, out, dout, lse, heads, dim_head=64):
+    lib = _lib.load()
+    qkv, out, dout, lse = _dev_bf16(qkv, "qkv"), _dev_bf16(out, "out"), _dev_bf16(dout, "dout"), _dev(lse, "lse")
+    B, N, _ = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B * heads * N, dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        rc = lib.dgvit_attention_backward_bf16(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), _ptr(delta), B, N, heads, dim_head,
+                                               _stream())
+    _lib.check(rc, "dgvit_attention_backward_bf16")
+    return dqkv
+
+
 class Bf16Weights:
     """bf16 copies of an encoder's GEMM weights in one arena (dgvit_got_pack_weights_bf16), re-packed only when a master
     parameter has changed (tensor version counters)."""

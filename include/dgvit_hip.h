@@ -219,8 +219,7 @@ int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* const* params, 
 /* Training in the bf16 configuration: forward with save_for_backward = 1 (dense last block), then
  *   dfeat (B, D) -> grads[] (fp32, table order of params, each written), dgoal (B, D) (may be NULL).
  * Gradients of GEMM operands travel bf16 (dY of every Linear), the residual-stream gradient, LayerNorm / bias / weight
- * gradients are fp32; weight gradients are fp32 split-K slabs summed in a fixed order (deterministic).  The attention
- * core's backward runs on the fp32 kernels of dgvit_attention_backward over fp32 copies of its bf16 operands.
+ * gradients are fp32; weight gradients are fp32 split-K slabs summed in a fixed order (deterministic).
  * `img` is the forward's input (the patch-embedding weight gradient re-gathers the patches in fp32);
  * scratch: dgvit_got_bf16_backward_scratch_bytes BYTES, 256-byte aligned. */
 long long dgvit_got_bf16_backward_scratch_bytes(const dgvit_config* cfg, int batch);
@@ -253,6 +252,10 @@ int dgvit_layernorm_forward_bf16(const float* x, const float* gamma, const float
 /* attention core on bf16 qkv (B, N, 3*H*64) -> bf16 out (B, N, H*64); lse fp32 (B, H, N) or NULL */
 int dgvit_attention_forward_bf16(const unsigned short* qkv, unsigned short* out, float* lse, int B, int N, int H, int dh,
                                  void* stream);
+/* gradient of the attention core: dqkv (B, N, 3*H*64) bf16 from qkv, the forward's out and lse, and dout; delta: B*H*N floats
+ * of scratch (rowsum(dout o out), handed from the dQ kernel to the dK/dV kernel) */
+int dgvit_attention_backward_bf16(const unsigned short* qkv, const unsigned short* out, const unsigned short* dout, const float* lse,
+                                  unsigned short* dqkv, float* delta, int B, int N, int H, int dh, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
  * Optional live kernel timing (HIP events on the launch stream around every kernel launch).

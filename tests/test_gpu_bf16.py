@@ -148,6 +148,25 @@ def test_attention_bf16_large_logits(F):
     close(out, ref, atol=1.5e-2, rtol=2 ** -7)
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 197, 12), (3, 50, 8), (2, 1, 2), (1, 32, 1), (2, 33, 3), (1, 224, 2), (4, 65, 4)])
+def test_attention_bwd_bf16(F, B, N, H):
+    dh = 64
+    I = H * dh
+    qkv = rb(rnd(B, N, 3 * I, seed=N + 1)).requires_grad_(True)
+    dout = rb(rnd(B, N, I, seed=N + 2))
+    q, k, v = (qkv[..., j * I:(j + 1) * I].reshape(B, N, H, dh).permute(0, 2, 1, 3) for j in range(3))
+    ref = (torch.softmax((q @ k.transpose(-1, -2)) * dh ** -0.5, -1) @ v).permute(0, 2, 1, 3).reshape(B, N, I)
+    (ref * dout).sum().backward()
+    out, lse = F.op_attention_bf16(dbf(qkv.detach()), H, dh, want_lse=True)
+    dqkv = F.op_attention_bwd_bf16(dbf(qkv.detach()), out, dbf(dout), lse, H, dh)
+    # P, dS and the forward output are bf16 operands of the gradient products; compare tensor-wise (relative L2) and element-wise
+    g, r = dqkv.double().cpu(), qkv.grad
+    for j, name in enumerate(("dq", "dk", "dv")):
+        gj, rj = g[..., j * I:(j + 1) * I], r[..., j * I:(j + 1) * I]
+        assert float((gj - rj).norm()) < 1.5e-2 * float(rj.norm()) + 1e-3, name   # (N = 1: dq and dk are exactly zero)
+    close(dqkv, qkv.grad, atol=6e-2, rtol=3e-2, msg=f"attention bwd B{B} N{N} H{H}")
+
+
 # ---------------------------------------------------------------------------------------------- encoder
 def _run_encoder(cfg, params, img, goal, prune=True):
     import dgvit_amd
