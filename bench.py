@@ -146,6 +146,25 @@ def c5_bf16(dgvit_amd, lib, _lib, dev, batch=256, steps=10):
     lib.dgvit_profile_stop(ms, work, cnt)
     fwd = synthetic.fwd_flops_per_frame((224, 224), (16, 16), 768, 12, 12, mlp_dim=3072)
     gemm_tf = (work[0] / 1e12) / (ms[0] / 1e3) if ms[0] > 0 else 0.0
+    # forward + backward in train mode (dense last block, activations kept, fp32 master gradients), no optimiser step
+    m.train()
+    tgt = torch.randn(batch, 768, generator=g).to(dev)
+
+    def fb():
+        for p_ in m.parameters():
+            p_.grad = None
+        ((m(img, goal) - tgt) ** 2).mean().backward()
+
+    for _ in range(2):
+        fb()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        fb()
+    torch.cuda.synchronize()
+    dtb = (time.perf_counter() - t0) / 5
+    train = {"frames_per_s": round(batch / dtb, 1), "ms_per_step": round(dtb * 1e3, 3), "tflops_dense": round(batch / dtb * 3 * fwd / 1e12, 1),
+             "frac_of_bf16_peak": round(batch / dtb * 3 * fwd / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
     return {"workload": f"C5: GoT 224x224@16x16, L12 H12 D768 M3072 (N=197), forward, batch {batch}, bf16 storage / fp32 accumulate",
             "frames_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "dtype": "bf16",
             "tflops_dense": round(batch / dt * fwd / 1e12, 1), "frac_of_bf16_peak": round(batch / dt * fwd / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
@@ -153,7 +172,7 @@ def c5_bf16(dgvit_amd, lib, _lib, dev, batch=256, steps=10):
                          "unit": "TFLOP/s", "frac": round(gemm_tf / PEAK_BF16_MFMA_TFLOPS, 4),
                          "avg_launch_ms": round(ms[0] / max(1, cnt[0]), 5), "launches_per_step": int(cnt[0] // steps)},
             "gemm_ms_per_step": round(ms[0] / steps, 3), "attn_fwd_ms_per_step": round(ms[1] / steps, 3),
-            "norm_ms_per_step": round(ms[3] / steps, 3)}
+            "norm_ms_per_step": round(ms[3] / steps, 3), "fwd_bwd": train}
 
 
 def main():

@@ -47,9 +47,10 @@ int add_layernorm_fwd_bf16(const float* x, const bf16_t* delta, float* xout, con
 int residual_add_bf16(const float* x, const bf16_t* delta, float* xout, int rows, int D, int rs, hipStream_t st);
 int layernorm_bwd_bf16(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
                        float* dx, bf16_t* dxb, float* dgamma, float* dbeta, float* partial, int T, int D, int rs, hipStream_t st);
-int transpose_bf16(const bf16_t* src, long long ld, bf16_t* dst, int rows, int cols, int ldd, hipStream_t st);
+int transpose_colsum_blocks(int rows);
+int colpart_reduce(const float* part, float* out, int rows, int cols, hipStream_t st);
+int transpose_bf16(const bf16_t* src, long long ld, bf16_t* dst, int rows, int cols, int ldd, float* colpart, hipStream_t st);
 int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int rows, int cols, hipStream_t st);
-int rowsum_bf16(const bf16_t* src, long long ld, float* out, int rows, int cols, hipStream_t st);
 int cast_bf16_f32(const bf16_t* src, float* dst, long long n, hipStream_t st);
 int attention_fwd_bf16(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N, int H, int dh, int nq, hipStream_t st);
 

@@ -822,6 +822,7 @@ Bsb make_bsb(const Dims& d) {
   long long part = (long long)layernorm_bwd_blocks((int)d.T) * 2 * d.D;
   part = std::max(part, (long long)colsum_blocks(d.B) * d.N * d.D);
   part = std::max(part, (long long)rmsnorm_bwd_blocks(d.B) * d.D);
+  part = std::max(part, (long long)transpose_colsum_blocks((int)d.T) * widest);   // bias-gradient partials of the dY transposes
   s.part = o; o += al128(part * 4);
   s.delta = o; o += al128((long long)d.B * d.H * d.N * 4);   // rowsum(dO o O) of the attention backward
   s.patches32 = o; o += al128((long long)d.B * d.P * d.pd * 4);
@@ -1019,10 +1020,11 @@ extern "C" int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* con
   float* part = (float*)(sc + s.part);
 
   // dW (no x ni) and optionally db (no) from dY (T x no, row stride ldy) and X (T x ni, row stride ldx)
+  // (the bias gradient = column sums of dY falls out of its transposition: per-row-block partials, then a fixed-order sum)
   auto wgrad = [&](const bf16_t* dY, int ldy, const bf16_t* X, int ldx, float* dW, float* db, int no, int ni) -> int {
-    TRY(transpose_bf16(dY, ldy, tA, T, no, Tp, st));
-    TRY(transpose_bf16(X, ldx, tB, T, ni, Tp, st));
-    if (db) TRY(rowsum_bf16(tA, Tp, db, no, Tp, st));
+    TRY(transpose_bf16(dY, ldy, tA, T, no, Tp, db ? part : nullptr, st));
+    TRY(transpose_bf16(X, ldx, tB, T, ni, Tp, nullptr, st));
+    if (db) TRY(colpart_reduce(part, db, T, no, st));
     return wgrad_bf16(tA, tB, dW, no, ni, Tp, slabs, s.slab_floats, st);
   };
 
@@ -1105,16 +1107,23 @@ extern "C" int dgvit_gemm_bf16(int epilogue, const unsigned short* A, int lda, c
   DGVIT_CHECK_ARG(epilogue != BEPI_DGELU_BF16 || aux, "dgvit_gemm_bf16: epilogue 3 needs aux");
   return gemm_bf16(epilogue, p, (hipStream_t)stream);
 }
-extern "C" long long dgvit_wgrad_bf16_scratch_floats(int Mo, int Ko, int T) { return wgrad_bf16_scratch(Mo, Ko, up8(T)); }
+extern "C" long long dgvit_wgrad_bf16_scratch_floats(int Mo, int Ko, int T) {
+  return wgrad_bf16_scratch(Mo, Ko, up8(T)) + (long long)transpose_colsum_blocks(T) * Mo;
+}
 extern "C" int dgvit_wgrad_bf16(const unsigned short* dY, const unsigned short* X, float* dW, float* db, unsigned short* tA,
                                 unsigned short* tB, float* slabs, long long slab_floats, int T, int Mo, int Ko, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   DGVIT_CHECK_ARG(dY && X && dW && tA && tB && T > 0 && Mo > 0 && Ko > 0 && Mo % 8 == 0 && Ko % 8 == 0, "dgvit_wgrad_bf16: bad arguments");
   const int Tp = up8(T);
-  TRY(transpose_bf16(dY, Mo, tA, T, Mo, Tp, st));
-  TRY(transpose_bf16(X, Ko, tB, T, Ko, Tp, st));
-  if (db) TRY(rowsum_bf16(tA, Tp, db, Mo, Tp, st));
-  return wgrad_bf16(tA, tB, dW, Mo, Ko, Tp, slabs, slab_floats, st);
+  // slabs layout: [split-K slabs | bias-gradient partials]
+  const long long nsl = wgrad_bf16_scratch(Mo, Ko, Tp), npart = db ? (long long)transpose_colsum_blocks(T) * Mo : 0;
+  if (slab_floats < nsl + npart) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "dgvit_wgrad_bf16: scratch %lld < %lld floats", slab_floats, nsl + npart);
+  DGVIT_CHECK_ARG(slabs || nsl + npart == 0, "dgvit_wgrad_bf16: null scratch");
+  float* part = slabs + nsl;
+  TRY(transpose_bf16(dY, Mo, tA, T, Mo, Tp, db ? part : nullptr, st));
+  TRY(transpose_bf16(X, Ko, tB, T, Ko, Tp, nullptr, st));
+  if (db) TRY(colpart_reduce(part, db, T, Mo, st));
+  return wgrad_bf16(tA, tB, dW, Mo, Ko, Tp, slabs, nsl, st);
 }
 extern "C" int dgvit_layernorm_forward_bf16(const float* x, const float* gamma, const float* beta, unsigned short* y, float* mean,
                                             float* rstd, int rows, int D, void* stream) {

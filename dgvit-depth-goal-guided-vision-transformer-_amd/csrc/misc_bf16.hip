@@ -180,9 +180,11 @@ __device__ __forceinline__ u32x4m load8(const SRC* p) {
   }
 }
 
+// colpart (optional): colpart[blockIdx.y][col] = sum of the tile's 64 source rows of that column (fp32, fixed order) -- the
+// partial column sums of dY, i.e. the bias gradient once the row blocks are added up (reduce_slabs).
 template <typename SRC>
 __global__ void __launch_bounds__(256) transpose_bf16_kernel(const SRC* __restrict__ src, long long ld, bf16_t* __restrict__ dst,
-                                                             int rows, int cols, int ldd) {
+                                                             int rows, int cols, int ldd, float* __restrict__ colpart) {
   __shared__ unsigned tile[64][33];   // [column][row pair]
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
@@ -200,6 +202,15 @@ __global__ void __launch_bounds__(256) transpose_bf16_kernel(const SRC* __restri
     }
   }
   __syncthreads();
+  if (colpart && tid < 64 && c0 + tid < cols) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int rp = 0; rp < 32; ++rp) {
+      const unsigned w = tile[tid][rp];
+      s += __builtin_bit_cast(float, w << 16) + __builtin_bit_cast(float, w & 0xFFFF0000u);
+    }
+    colpart[(long long)blockIdx.y * cols + c0 + tid] = s;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int f = tid + i * 256, c = f >> 3, r8 = (f & 7) * 8;   // output row c0 + c, output columns r0 + r8 .. + 7
@@ -212,26 +223,6 @@ __global__ void __launch_bounds__(256) transpose_bf16_kernel(const SRC* __restri
   }
 }
 
-// out[r] = sum_c src[r][c] (fp32 accumulation, fixed order): bias gradients from the transposed dY copies
-__global__ void __launch_bounds__(256) rowsum_bf16_kernel(const bf16_t* __restrict__ src, long long ld, float* __restrict__ out, int cols) {
-  __shared__ float red[4];
-  const bf16_t* row = src + (long long)blockIdx.x * ld;
-  float s = 0.f;
-  for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
-    if (c + 8 <= cols) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += (float)v[j];
-    } else {
-      for (int j = c; j < cols; ++j) s += bf16_to_f32(row[j]);
-    }
-  }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) out[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
-}
-
 __global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long long n4) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
@@ -240,12 +231,50 @@ __global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const bf16_t* __rest
 
 }  // namespace
 
-int transpose_bf16(const bf16_t* src, long long ld, bf16_t* dst, int rows, int cols, int ldd, hipStream_t st) {
+int transpose_colsum_blocks(int rows) { return (((rows + 7) & ~7) + 63) / 64; }
+
+namespace {
+// out[c] = sum over the nblk row-block partials of column c; 64 columns x 16 row lanes per workgroup, fixed order
+__global__ void __launch_bounds__(1024) colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int cols) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, c = blockIdx.x * 64 + tx;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    int z = ty;
+    for (; z + 16 < nblk; z += 32) {
+      s0 += part[(long long)z * cols + c];
+      s1 += part[(long long)(z + 16) * cols + c];
+    }
+    if (z < nblk) s0 += part[(long long)z * cols + c];
+  }
+  red[ty][tx] = s0 + s1;
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][tx];
+    out[c] = s;
+  }
+}
+}  // namespace
+
+// out (cols) = sum of the transpose_colsum_blocks(rows) partial rows written by transpose_bf16(colpart)
+int colpart_reduce(const float* part, float* out, int rows, int cols, hipStream_t st) {
+  DGVIT_CHECK_ARG(part && out && rows > 0 && cols > 0, "colpart_reduce: bad arguments");
+  const int slot = profile_begin(PROF_OTHER, 0.0, st);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((cols + 63) / 64), dim3(1024), 0, st, part, out, transpose_colsum_blocks(rows), cols);
+  profile_end(slot, st);
+  DGVIT_CHECK_LAUNCH("colpart_reduce");
+  return DGVIT_OK;
+}
+
+// colpart: null, or transpose_colsum_blocks(rows) * cols floats receiving the per-row-block column sums of src
+int transpose_bf16(const bf16_t* src, long long ld, bf16_t* dst, int rows, int cols, int ldd, float* colpart, hipStream_t st) {
   DGVIT_CHECK_ARG(src && dst && rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0, "transpose_bf16: cols and ld must be multiples of 8");
   DGVIT_CHECK_ARG(ldd >= rows && ldd % 8 == 0 && ldd - rows < 8, "transpose_bf16: ldd must be rows rounded up to a multiple of 8");
   const int slot = profile_begin(PROF_OTHER, 0.0, st);
   hipLaunchKernelGGL((transpose_bf16_kernel<bf16_t>), dim3((cols + 63) / 64, (ldd + 63) / 64), dim3(256), 0, st, src, ld, dst, rows, cols,
-                     ldd);
+                     ldd, colpart);
   profile_end(slot, st);
   DGVIT_CHECK_LAUNCH("transpose_bf16");
   return DGVIT_OK;
@@ -255,17 +284,8 @@ int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int rows, int cols, h
   DGVIT_CHECK_ARG(src && dst && rows > 0 && cols > 0 && cols % 8 == 0 && rows % 8 == 0,
                   "transpose_cast_f32_bf16: rows and cols must be multiples of 8");
   hipLaunchKernelGGL((transpose_bf16_kernel<float>), dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, src, (long long)cols, dst,
-                     rows, cols, rows);
+                     rows, cols, rows, (float*)nullptr);
   DGVIT_CHECK_LAUNCH("transpose_cast_f32_bf16");
-  return DGVIT_OK;
-}
-
-int rowsum_bf16(const bf16_t* src, long long ld, float* out, int rows, int cols, hipStream_t st) {
-  DGVIT_CHECK_ARG(src && out && rows > 0 && cols > 0 && ld % 8 == 0, "rowsum_bf16: bad arguments");
-  const int slot = profile_begin(PROF_OTHER, 0.0, st);
-  hipLaunchKernelGGL(rowsum_bf16_kernel, dim3(rows), dim3(256), 0, st, src, ld, out, cols);
-  profile_end(slot, st);
-  DGVIT_CHECK_LAUNCH("rowsum_bf16");
   return DGVIT_OK;
 }
 
