@@ -32,6 +32,7 @@ struct GemmBf16Params {
   const bf16_t* aux; int ldaux; // BEPI_DGELU_BF16
   int ksplit, kchunk;           // ksplit > 1: K is cut into ksplit slices of kchunk (multiple of 32); slice z writes C + z * slab_stride
   long long slab_stride;        //             (BEPI_F32_PLAIN only; the slabs are summed by reduce_slabs)
+  int tn;                       // 1: A is (K, M) with row stride lda, B is (K, N): C = A^T B (BEPI_F32_PLAIN, 256 x 256 tile)
 };
 
 int gemm_bf16(int epi, const GemmBf16Params& p, hipStream_t st);
@@ -47,6 +48,8 @@ int add_layernorm_fwd_bf16(const float* x, const bf16_t* delta, float* xout, con
 int residual_add_bf16(const float* x, const bf16_t* delta, float* xout, int rows, int D, int rs, hipStream_t st);
 int layernorm_bwd_bf16(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
                        float* dx, bf16_t* dxb, float* dgamma, float* dbeta, float* partial, int T, int D, int rs, hipStream_t st);
+int colsum_bf16_blocks(int rows);
+int colsum_bf16(const bf16_t* src, long long ld, float* out, float* part, int rows, int cols, hipStream_t st);
 int transpose_colsum_blocks(int rows);
 int colpart_reduce(const float* part, float* out, int rows, int cols, hipStream_t st);
 int transpose_bf16(const bf16_t* src, long long ld, bf16_t* dst, int rows, int cols, int ldd, float* colpart, hipStream_t st);

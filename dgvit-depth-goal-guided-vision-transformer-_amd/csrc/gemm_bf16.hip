@@ -226,8 +226,15 @@ typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 // STAMP: diagnostic build (tools/bf16_stamps.py): wave 0 / wave 4 lane 0 of every workgroup write s_memtime at the start
 // of each of its first 8 tiles, after the tile's main loop and after its epilogue, to a buffer nothing else reads.
 // The shipped instantiations have STAMP = false (no stamp executes).
-template <class T, int EPI, bool STAMP = false>
+// TN: both operands are stored contraction-major -- A (K x M, row stride lda), B (K x N): the weight gradient
+// dW = dY^T X straight from the token-major activations, no transposed copies.  A k-tile is then 32 rows x 512 bytes per
+// operand (one DMA instruction = 2 rows; 16-byte chunk c of row r stored at chunk c ^ ((r & 3) << 2)), and a fragment is
+// two `ds_read_b64_tr_b16`: per 16-lane group the hardware reads a 4 (k) x 16 (m) block and hands lane i column i, so a
+// lane gets 4 consecutive k of its own m -- exactly the MFMA operand order.  The swizzle puts the block's 4 rows on the
+// four 64-byte bank groups: a 32-lane half (two blocks) touches every bank once.
+template <class T, int EPI, bool STAMP = false, bool TN = false>
 __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Params p, int ntiles, long long* stamps = nullptr) {
+  static_assert(!TN || (T::BM == 256 && T::BN == 256), "the TN layout is built for the 256 x 256 tile");
   constexpr int BM = T::BM, BN = T::BN, MT = T::MT, NTL = T::NTL, WTM = T::WTM, WTN = T::WTN;
   using R = Ring<T, EPI>;
   constexpr int NS = R::NS, D = R::D;
@@ -245,37 +252,68 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   // ---- load side: runs D k-tiles ahead of the compute side, across tile boundaries ---------------------------
   // one DMA instruction fills 16 rows x 64 bytes: lane -> row lane >> 2, physical chunk lane & 3, which holds logical
   // chunk (lane & 3) ^ ((row >> 2) & 3); 16-row groups keep (row >> 2) & 3 == (lane >> 4) & 3
-  const int srow = lane >> 2;
-  const int sc = (lane & 3) ^ ((lane >> 4) & 3);
-  const unsigned offA = ((unsigned)(wave * 16 + srow) * (unsigned)p.lda + sc * 8u) * 2u;
-  const unsigned offB = ((unsigned)(wave * 16 + srow) * (unsigned)p.ldb + sc * 8u) * 2u;
-  const unsigned stepA = 128u * (unsigned)p.lda * 2u, stepB = 128u * (unsigned)p.ldb * 2u;   // 8 waves x 16 rows
+  // (TN: one instruction fills 2 k-rows x 512 bytes: lane -> row lane >> 5 of the pair, physical chunk lane & 31 holding
+  //  logical chunk (lane & 31) ^ ((row & 3) << 2); wave w owns the row pairs w and w + 8, so row & 3 = 2 (w & 1) + (lane >> 5))
+  const int srow = TN ? (lane >> 5) : (lane >> 2);
+  const int sc = TN ? ((lane & 31) ^ (((2 * (wave & 1) + (lane >> 5)) & 3) << 2)) : ((lane & 3) ^ ((lane >> 4) & 3));
+  const unsigned offA = ((unsigned)(wave * (TN ? 2 : 16) + srow) * (unsigned)p.lda + sc * 8u) * 2u;
+  const unsigned offB = ((unsigned)(wave * (TN ? 2 : 16) + srow) * (unsigned)p.ldb + sc * 8u) * 2u;
+  // distance between a wave's DMA instructions of one k-tile: NT 128 tile rows, TN 16 k-rows
+  const unsigned stepA = (TN ? 16u : 128u) * (unsigned)p.lda * 2u, stepB = (TN ? 16u : 128u) * (unsigned)p.ldb * 2u;
   int ltile = blockIdx.x, lt = 0, lslot = 0, lklen = 0, lnkt = 1;
+  bool la_ok = true, lb_ok = true;   // TN: this lane's 8 columns lie inside the matrix (M, N % 8 == 0)
   __amdgpu_buffer_rsrc_t rsA, rsB;
   auto set_load_tile = [&](int v) {
     const int vt = xcd_chunk(v, ntiles), tile = vt / S, k0 = (vt % S) * kchunk;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     lklen = slice_len(vt % S);
     lnkt = (lklen + 31) / 32;
-    long long abytes = ((long long)(p.M - 1 - m0) * p.lda + lklen) * 2, bbytes = ((long long)(p.N - 1 - n0) * p.ldb + lklen) * 2;
+    long long abytes, bbytes;
+    if (TN) {
+      abytes = ((long long)(lklen - 1) * p.lda + (p.M - m0)) * 2;
+      bbytes = ((long long)(lklen - 1) * p.ldb + (p.N - n0)) * 2;
+      la_ok = m0 + sc * 8 < p.M;
+      lb_ok = n0 + sc * 8 < p.N;
+    } else {
+      abytes = ((long long)(p.M - 1 - m0) * p.lda + lklen) * 2;
+      bbytes = ((long long)(p.N - 1 - n0) * p.ldb + lklen) * 2;
+    }
     if (abytes > 0x7FFFFFF0ll) abytes = 0x7FFFFFF0ll;
     if (bbytes > 0x7FFFFFF0ll) bbytes = 0x7FFFFFF0ll;
-    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + (long long)m0 * p.lda + k0), 0, (int)abytes, 0x00020000);
-    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B + (long long)n0 * p.ldb + k0), 0, (int)bbytes, 0x00020000);
+    const long long a0 = TN ? (long long)k0 * p.lda + m0 : (long long)m0 * p.lda + k0;
+    const long long b0 = TN ? (long long)k0 * p.ldb + n0 : (long long)n0 * p.ldb + k0;
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + a0), 0, (int)abytes, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B + b0), 0, (int)bbytes, 0x00020000);
   };
   set_load_tile(ltile);   // blockIdx.x < ntiles by construction of the grid
   auto issue_next = [&]() {
     // past the last tile the same instructions still issue (every lane out of range, zeros into a free slot): the
     // vmcnt bookkeeping then is the same for every stream length
-    const unsigned dead = (ltile < ntiles && lt * 32 + sc * 8 < lklen) ? 0u : DGVIT_BUF_OOB;
-    const unsigned oa = (offA + (unsigned)lt * 64u) | dead, ob = (offB + (unsigned)lt * 64u) | dead;
     unsigned char* dst = smem + lslot * R::SLOT + wave * 1024;
+    if constexpr (TN) {
+      const bool live = ltile < ntiles;
+      const unsigned base_a = offA + (unsigned)lt * 32u * (unsigned)p.lda * 2u, base_b = offB + (unsigned)lt * 32u * (unsigned)p.ldb * 2u;
 #pragma unroll
-    for (int i = 0; i < R::GA; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + i * 8192), 16, oa + i * stepA, 0, 0, 0);
+      for (int i = 0; i < 2; ++i) {   // k-rows lt * 32 + 2 * wave + srow + 16 i
+        const bool rok = live && lt * 32 + 2 * wave + srow + 16 * i < lklen;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + i * 8192), 16, (rok && la_ok) ? base_a + i * stepA : DGVIT_BUF_OOB, 0, 0, 0);
+      }
 #pragma unroll
-    for (int i = 0; i < R::GB; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + BM * 64 + i * 8192), 16, ob + i * stepB, 0, 0, 0);
+      for (int i = 0; i < 2; ++i) {
+        const bool rok = live && lt * 32 + 2 * wave + srow + 16 * i < lklen;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + 16384 + i * 8192), 16, (rok && lb_ok) ? base_b + i * stepB : DGVIT_BUF_OOB, 0, 0,
+                                                 0);
+      }
+    } else {
+      const unsigned dead = (ltile < ntiles && lt * 32 + sc * 8 < lklen) ? 0u : DGVIT_BUF_OOB;
+      const unsigned oa = (offA + (unsigned)lt * 64u) | dead, ob = (offB + (unsigned)lt * 64u) | dead;
+#pragma unroll
+      for (int i = 0; i < R::GA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(dst + i * 8192), 16, oa + i * stepA, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < R::GB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(dst + BM * 64 + i * 8192), 16, ob + i * stepB, 0, 0, 0);
+    }
     lslot = lslot + 1 == NS ? 0 : lslot + 1;
     if (++lt == lnkt) {
       lt = 0;
@@ -289,6 +327,25 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   const unsigned fsw = (unsigned)((li >> 2) & 3);
   const unsigned a_l0 = (unsigned)(wr * WTM + li) * 64u + ((h ^ fsw) * 16u);
   const unsigned b_l0 = (unsigned)(BM + wc * WTN + li) * 64u + ((h ^ fsw) * 16u);
+  // TN transposed reads: lane 4q + p of a 16-lane group addresses row q of the 4 x 16 block, columns 4p .. 4p+3; the block of
+  // k-step s, half u, 32-column tile X is rows 16 s + 8 h + 4 u + (0..3), columns 32 X + 16 ((lane >> 4) & 1) + (0..15)
+  const unsigned tq = (unsigned)((lane & 15) >> 2), tp = (unsigned)(lane & 3), tcb = (unsigned)((lane >> 4) & 1);
+  auto tr_base = [&](unsigned region, unsigned X) {   // byte address of (s = 0, u = 0) for 32-column tile X of an operand region
+    return region + (8u * h + tq) * 512u + ((((X ^ tq) << 2) | (2u * tcb + (tp >> 1))) * 16u) + (tp & 1u) * 8u;
+  };
+  unsigned ta[TN ? MT : 1], tb[TN ? NTL : 1];
+  if constexpr (TN) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) ta[i] = tr_base(0u, (unsigned)(wr * (WTM / 32) + i));
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) tb[j] = tr_base(16384u, (unsigned)(wc * (WTN / 32) + j));
+  }
+  auto tr_frag = [&](const unsigned char* sb, unsigned base, int s) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sb + base + s * 8192));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sb + base + s * 8192 + 2048));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
   float* es = reinterpret_cast<float*>(smem + NS * R::SLOT + wave * R::EPW);
   constexpr int LPR = WTN / 4, RPI = 64 / LPR;   // lanes per output row piece, rows per staging read
   const int erow = lane / LPR, ecol = (lane % LPR) * 4;
@@ -311,10 +368,17 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
     bf16x8 af[2][MT], bf[2][NTL];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+      if constexpr (TN) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(sb + (a_l0 ^ (s * 32u)) + i * 2048);
+        for (int i = 0; i < MT; ++i) af[s][i] = tr_frag(sb, ta[i], s);
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) bf[s][j] = *reinterpret_cast<const bf16x8*>(sb + (b_l0 ^ (s * 32u)) + j * 2048);
+        for (int j = 0; j < NTL; ++j) bf[s][j] = tr_frag(sb, tb[j], s);
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(sb + (a_l0 ^ (s * 32u)) + i * 2048);
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) bf[s][j] = *reinterpret_cast<const bf16x8*>(sb + (b_l0 ^ (s * 32u)) + j * 2048);
+      }
     }
     issue_next();
     if (since_epi < D - 1) wait_vmcnt<R::WAIT_EPI>(); else wait_vmcnt<R::WAIT>();
@@ -494,11 +558,28 @@ int launch(const GemmBf16Params& p, hipStream_t st) {
         return DGVIT_OK;
       }
     }
+    if constexpr (EPI == BEPI_F32_PLAIN && T::BM == 256 && T::BN == 256) {
+      if (p.tn) {   // contraction-major operands (weight gradients)
+        static bool tn_attr = false;
+        if (!tn_attr) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<T, EPI, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit");
+          tn_attr = true;
+        }
+        const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, st);
+        hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI, false, true>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, (long long*)nullptr);
+        profile_end(slot, st);
+        DGVIT_CHECK_LAUNCH("gemm_bf16_ring_kernel(TN)");
+        return DGVIT_OK;
+      }
+    }
+    DGVIT_CHECK_ARG(!p.tn, "gemm_bf16: the TN layout needs the plain fp32 epilogue and the 256 x 256 tile");
     const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, st);
     hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, (long long*)nullptr);
     profile_end(slot, st);
   } else {
-    DGVIT_CHECK_ARG(p.ksplit <= 1, "gemm_bf16: split-K needs a 256-row tile");
+    DGVIT_CHECK_ARG(p.ksplit <= 1 && !p.tn, "gemm_bf16: split-K / TN need the 256 x 256 tile");
     if (!attr_done) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               T::LDS) != hipSuccess)
@@ -519,7 +600,7 @@ int dispatch(const GemmBf16Params& p, hipStream_t st) {
   int tile = g_gemm_bf16_tile_hint;
   if (!tile) {
     const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    tile = (p.ksplit > 1 || (p.M >= 256 && p.N >= 256 && t256 >= 512)) ? 256256 : 128128;
+    tile = (p.ksplit > 1 || p.tn || (p.M >= 256 && p.N >= 256 && t256 >= 512)) ? 256256 : 128128;
   }
   switch (tile) {
     case 256256: return launch<BTile<256, 256, 2, 4>, EPI, true>(p, st);
@@ -533,12 +614,15 @@ int dispatch(const GemmBf16Params& p, hipStream_t st) {
 
 int gemm_bf16(int epi, const GemmBf16Params& p, hipStream_t st) {
   DGVIT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm_bf16: empty problem %d x %d x %d", p.M, p.N, p.K);
-  DGVIT_CHECK_ARG(p.K % 8 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0, "gemm_bf16: K, lda, ldb must be multiples of 8 (16-byte rows)");
+  DGVIT_CHECK_ARG(p.lda % 8 == 0 && p.ldb % 8 == 0 && (p.tn ? (p.M % 8 == 0 && p.N % 8 == 0) : p.K % 8 == 0),
+                  "gemm_bf16: leading dimensions and the contiguous extents (K; TN: M, N) must be multiples of 8 (16-byte chunks)");
   DGVIT_CHECK_ARG(p.N % 4 == 0 && p.ldc % 4 == 0, "gemm_bf16: N and ldc must be multiples of 4");
   DGVIT_CHECK_ARG(((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.C2 | (uintptr_t)p.aux) % 16 == 0,
                   "gemm_bf16: operands must be 16-byte aligned");
   DGVIT_CHECK_ARG((!p.res || p.ldr % 4 == 0) && (epi != BEPI_DGELU_BF16 || (p.aux && p.ldaux % 4 == 0)), "gemm_bf16: bad residual / aux");
   DGVIT_CHECK_ARG((long long)p.lda * 2 * 256 < (1ll << 30) && (long long)p.ldb * 2 * 256 < (1ll << 30), "gemm_bf16: leading dimension too large");
+  DGVIT_CHECK_ARG(!p.tn || (long long)(p.ksplit > 1 ? p.kchunk : p.K) * (p.lda > p.ldb ? p.lda : p.ldb) * 2 < (1ll << 31),
+                  "gemm_bf16: TN k-slice too long for 32-bit buffer offsets (split K further)");
   switch (epi) {
     case BEPI_BF16: return dispatch<BEPI_BF16>(p, st);
     case BEPI_GELU_BF16: return dispatch<BEPI_GELU_BF16>(p, st);

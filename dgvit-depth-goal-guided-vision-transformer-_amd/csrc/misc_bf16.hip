@@ -233,6 +233,33 @@ __global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const bf16_t* __rest
 
 int transpose_colsum_blocks(int rows) { return (((rows + 7) & ~7) + 63) / 64; }
 
+// ---- column sums of a bf16 matrix (bias gradient db[n] = sum_t dY[t][n]): row-block partials, then colpart_reduce
+namespace {
+// grid (ceil(cols / 512), nblk); 256 threads = 64 column chunks of 8 x 4 row lanes; partial[blockIdx.y][col]
+__global__ void __launch_bounds__(256) colsum_bf16_kernel(const bf16_t* __restrict__ src, long long ld, float* __restrict__ part, int rows,
+                                                          int cols, int rows_per_blk) {
+  __shared__ float red[4][512];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6, c = blockIdx.x * 512 + tx * 8;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < cols) {
+    const int r1 = min(rows, (int)(blockIdx.y + 1) * rows_per_blk);
+    for (int r = blockIdx.y * rows_per_blk + ty; r < r1; r += 4) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (long long)r * ld + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[ty][tx * 8 + j] = s[j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 512; i += 256)
+    if (blockIdx.x * 512 + i < cols)
+      part[(long long)blockIdx.y * cols + blockIdx.x * 512 + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+}
+}  // namespace
+
+int colsum_bf16_blocks(int rows) { return rows < 4096 ? 1 : (rows < 65536 ? 64 : 256); }
+
 namespace {
 // out[c] = sum over the nblk row-block partials of column c; 64 columns x 16 row lanes per workgroup, fixed order
 __global__ void __launch_bounds__(1024) colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int cols) {
@@ -258,14 +285,29 @@ __global__ void __launch_bounds__(1024) colpart_reduce_kernel(const float* __res
 }
 }  // namespace
 
-// out (cols) = sum of the transpose_colsum_blocks(rows) partial rows written by transpose_bf16(colpart)
-int colpart_reduce(const float* part, float* out, int rows, int cols, hipStream_t st) {
-  DGVIT_CHECK_ARG(part && out && rows > 0 && cols > 0, "colpart_reduce: bad arguments");
+// out (cols) = sum of nblk partial rows
+static int colpart_reduce_n(const float* part, float* out, int nblk, int cols, hipStream_t st) {
+  DGVIT_CHECK_ARG(part && out && nblk > 0 && cols > 0, "colpart_reduce: bad arguments");
   const int slot = profile_begin(PROF_OTHER, 0.0, st);
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((cols + 63) / 64), dim3(1024), 0, st, part, out, transpose_colsum_blocks(rows), cols);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3((cols + 63) / 64), dim3(1024), 0, st, part, out, nblk, cols);
   profile_end(slot, st);
   DGVIT_CHECK_LAUNCH("colpart_reduce");
   return DGVIT_OK;
+}
+// ... of the transpose_colsum_blocks(rows) partial rows written by transpose_bf16(colpart)
+int colpart_reduce(const float* part, float* out, int rows, int cols, hipStream_t st) {
+  return colpart_reduce_n(part, out, transpose_colsum_blocks(rows), cols, st);
+}
+
+// out[c] = sum_r src[r][c]; part: colsum_bf16_blocks(rows) * cols floats
+int colsum_bf16(const bf16_t* src, long long ld, float* out, float* part, int rows, int cols, hipStream_t st) {
+  DGVIT_CHECK_ARG(src && out && part && rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0, "colsum_bf16: cols and ld must be multiples of 8");
+  const int nblk = colsum_bf16_blocks(rows), rpb = (rows + nblk - 1) / nblk;
+  const int slot = profile_begin(PROF_OTHER, 0.0, st);
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((cols + 511) / 512, nblk), dim3(256), 0, st, src, ld, part, rows, cols, rpb);
+  profile_end(slot, st);
+  DGVIT_CHECK_LAUNCH("colsum_bf16");
+  return colpart_reduce_n(part, out, nblk, cols, st);
 }
 
 // colpart: null, or transpose_colsum_blocks(rows) * cols floats receiving the per-row-block column sums of src

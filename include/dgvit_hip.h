@@ -240,6 +240,9 @@ int dgvit_cast_f32_bf16(const float* src, unsigned short* dst, long long n, void
 int dgvit_gemm_bf16(int epilogue, const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, int M,
                     int N, int K, const float* bias, const float* res, int ldr, unsigned short* C2, int ldc2,
                     const unsigned short* aux, int ldaux, void* stream);
+/* A/B knob (default 0): 1 = weight gradients through token-contiguous transposed copies + the NT kernel instead of the
+ * TN-layout kernel (transposed LDS reads, no copies) */
+void dgvit_set_wgrad_bf16_transposes(int on);
 /* test/bench knob: force the bf16 GEMM workgroup tile (0 = automatic; 256256, 256128, 128128) */
 void dgvit_set_gemm_bf16_tile(int tile);
 /* diagnostic (tools/bf16_stamps.py): non-NULL = the epilogue-0 ring GEMM runs its stamped build and writes, per workgroup,
