@@ -370,7 +370,11 @@ int attention_fwd_bf16(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N,
   const float scale = 1.0f / sqrtf((float)dh);
   const double flops = 4.0 * (double)nq * N * dh * H * B;
   const int slot = profile_begin(PROF_ATTN_FWD, flops, st);
-  hipLaunchKernelGGL((attn_fwd_bf16_kernel<4>), dim3((unsigned)((long long)B * H)), dim3(256), lds, st, qkv, out, lse, N, H, scale, nq);
+  // one wave per 32-query tile: 8 waves when there are more than 4 tiles (N = 197: 7 tiles), else 4
+  if ((nq + 31) / 32 > 4)
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<8>), dim3((unsigned)((long long)B * H)), dim3(512), lds, st, qkv, out, lse, N, H, scale, nq);
+  else
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<4>), dim3((unsigned)((long long)B * H)), dim3(256), lds, st, qkv, out, lse, N, H, scale, nq);
   profile_end(slot, st);
   DGVIT_CHECK_LAUNCH("attn_fwd_bf16_kernel");
   return DGVIT_OK;

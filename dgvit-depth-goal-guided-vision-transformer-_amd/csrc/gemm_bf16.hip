@@ -247,6 +247,17 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   // slice z covers k in [z * kchunk, min(K, (z + 1) * kchunk)) and writes its partial sums to slab z of C
   const int S = p.ksplit > 1 ? p.ksplit : 1;
   const int kchunk = S > 1 ? p.kchunk : ((p.K + 31) & ~31);
+  // tile order inside an XCD's chunk: groups of GROUP_M row panels walked column by column, so that the ~32 tiles an XCD
+  // runs at a time cover 8 row panels x 4 column panels (their A and B k-slices share the 4 MB L2) instead of 3-4 row
+  // panels x every column panel (a 3.5-4.7 MB weight matrix alone overflows the L2)
+  const int tiles_m = (p.M + BM - 1) / BM;
+  auto tile_mn = [&](int t, int& m0, int& n0) {
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n, grp_i = t / per_group, within = t - grp_i * per_group;
+    const int rows = tiles_m - grp_i * GROUP_M < GROUP_M ? tiles_m - grp_i * GROUP_M : GROUP_M;
+    m0 = (grp_i * GROUP_M + within % rows) * BM;
+    n0 = (within / rows) * BN;
+  };
   auto slice_len = [&](int z) { const int rem = p.K - z * kchunk; return rem < kchunk ? rem : kchunk; };
 
   // ---- load side: runs D k-tiles ahead of the compute side, across tile boundaries ---------------------------
@@ -265,7 +276,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   __amdgpu_buffer_rsrc_t rsA, rsB;
   auto set_load_tile = [&](int v) {
     const int vt = xcd_chunk(v, ntiles), tile = vt / S, k0 = (vt % S) * kchunk;
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    int m0, n0;
+    tile_mn(tile, m0, n0);
     lklen = slice_len(vt % S);
     lnkt = (lklen + 31) / 32;
     long long abytes, bbytes;
@@ -415,7 +427,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
     if constexpr (STAMP) st1 = __builtin_amdgcn_s_memtime();
     {
       const int vt = xcd_chunk(ctile, ntiles), tile = vt / S;
-      const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+      int m0, n0;
+      tile_mn(tile, m0, n0);
       const int gn = n0 + wc * WTN + ecol;
       const bool ncol = gn < p.N;
       // tile-relative buffer addressing: offsets stay small, invalid rows / columns are sent out of range
