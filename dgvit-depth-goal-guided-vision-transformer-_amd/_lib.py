@@ -70,11 +70,10 @@ SIGNATURES = {
     "dgvit_got_bf16_backward_scratch_bytes": (_LL, [_CFG, _I]),
     "dgvit_got_backward_bf16": (_I, [_CFG, _TABLE, _P, _TABLE, _P, _P, _P, _P, _LL, _P, _LL, _I, _F, _ULL, _P, _P]),
     "dgvit_wgrad_bf16_scratch_floats": (_LL, [_I, _I, _I]),
-    "dgvit_wgrad_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _P]),
+    "dgvit_wgrad_bf16": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _P]),
     "dgvit_cast_f32_bf16": (_I, [_P, _P, _LL, _P]),
     "dgvit_gemm_bf16": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     "dgvit_set_gemm_bf16_tile": (None, [_I]),
-    "dgvit_set_wgrad_bf16_transposes": (None, [_I]),
     "dgvit_set_gemm_bf16_stamps": (None, [_P]),
     "dgvit_layernorm_forward_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dgvit_attention_forward_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

@@ -50,9 +50,6 @@ int layernorm_bwd_bf16(const bf16_t* dy, const float* x, const float* mean, cons
                        float* dx, bf16_t* dxb, float* dgamma, float* dbeta, float* partial, int T, int D, int rs, hipStream_t st);
 int colsum_bf16_blocks(int rows);
 int colsum_bf16(const bf16_t* src, long long ld, float* out, float* part, int rows, int cols, hipStream_t st);
-int transpose_colsum_blocks(int rows);
-int colpart_reduce(const float* part, float* out, int rows, int cols, hipStream_t st);
-int transpose_bf16(const bf16_t* src, long long ld, bf16_t* dst, int rows, int cols, int ldd, float* colpart, hipStream_t st);
 int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int rows, int cols, hipStream_t st);
 int cast_bf16_f32(const bf16_t* src, float* dst, long long n, hipStream_t st);
 int attention_fwd_bf16(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N, int H, int dh, int nq, hipStream_t st);

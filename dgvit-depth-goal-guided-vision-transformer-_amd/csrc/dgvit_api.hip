@@ -776,22 +776,6 @@ long long wgrad_bf16_scratch(int Mo, int Ko, int Tp) {
   const SplitPlan pl = wgrad_bf16_plan(Mo, Ko, Tp);
   return pl.splits > 1 ? pl.splits * pl.slab : 0;
 }
-// dW (Mo x Ko, fp32) = At (Mo x Tp) Bt (Ko x Tp)^T with the token dimension contiguous (transposed bf16 copies, zero padded to Tp)
-int wgrad_bf16(const bf16_t* At, const bf16_t* Bt, float* dW, int Mo, int Ko, int Tp, float* slabs, long long slab_floats,
-               hipStream_t st) {
-  const SplitPlan pl = wgrad_bf16_plan(Mo, Ko, Tp);
-  if (pl.splits == 1) {
-    GemmBf16Params p = gpb(At, Tp, Bt, Tp, dW, Ko, Mo, Ko, Tp);
-    return gemm_bf16(BEPI_F32_PLAIN, p, st);
-  }
-  if (slab_floats < pl.splits * pl.slab)
-    return dgvit_set_error(DGVIT_ERR_WORKSPACE, "wgrad_bf16: slabs %lld < %lld floats", slab_floats, pl.splits * pl.slab);
-  GemmBf16Params p = gpb(At, Tp, Bt, Tp, slabs, Ko, Mo, Ko, Tp);
-  p.ksplit = pl.splits; p.kchunk = pl.kchunk; p.slab_stride = pl.slab;
-  TRY(gemm_bf16(BEPI_F32_PLAIN, p, st));
-  return reduce_slabs(slabs, dW, (long long)Mo * Ko, pl.splits, pl.slab, st);
-}
-
 // dW (Mo x Ko, fp32) = dY^T X straight from the token-major bf16 activations dY (T x Mo, row stride ldy), X (T x Ko, ldx):
 // the TN layout of the ring GEMM (transposed LDS reads), split over tokens
 int wgrad_bf16_tn(const bf16_t* dY, int ldy, const bf16_t* X, int ldx, float* dW, int Mo, int Ko, int T, float* slabs, long long slab_floats,
@@ -810,13 +794,11 @@ int wgrad_bf16_tn(const bf16_t* dY, int ldy, const bf16_t* X, int ldx, float* dW
 
 // backward scratch in BYTES
 struct Bsb {
-  long long dxa, dxb, dxh, dln, dqkv, dao, dh1, tA, tB, slabs, part, delta, patches32, total;
+  long long dxa, dxb, dxh, dln, dqkv, dao, dh1, slabs, part, delta, patches32, total;
   long long slab_floats;
-  int Tp;
 };
 Bsb make_bsb(const Dims& d) {
   Bsb s;
-  s.Tp = up8(d.T);
   long long o = 0;
   s.dxa = o; o += al128(d.T * d.D * 4);
   s.dxb = o; o += al128(d.T * d.D * 4);
@@ -826,20 +808,18 @@ Bsb make_bsb(const Dims& d) {
   s.dao = o; o += al128(d.T * d.I * 2);
   s.dh1 = o; o += al128(d.T * d.M * 2);
   const long long widest = std::max<long long>(std::max(3 * d.I, d.M), d.D);
-  s.tA = o; o += al128(widest * s.Tp * 2);
-  s.tB = o; o += al128(widest * s.Tp * 2);
-  long long sl = wgrad_bf16_scratch(3 * d.I, d.D, s.Tp);
-  sl = std::max(sl, wgrad_bf16_scratch(d.D, d.I, s.Tp));
-  sl = std::max(sl, wgrad_bf16_scratch(d.M, d.D, s.Tp));
-  sl = std::max(sl, wgrad_bf16_scratch(d.D, d.M, s.Tp));
+  const int Ti = (int)d.T;
+  long long sl = wgrad_bf16_scratch(3 * d.I, d.D, Ti);
+  sl = std::max(sl, wgrad_bf16_scratch(d.D, d.I, Ti));
+  sl = std::max(sl, wgrad_bf16_scratch(d.M, d.D, Ti));
+  sl = std::max(sl, wgrad_bf16_scratch(d.D, d.M, Ti));
   sl = std::max(sl, wgrad_scratch(d.D, d.pd, d.B * d.P));   // fp32 patch-embedding weight gradient
   s.slab_floats = sl;
   s.slabs = o; o += al128(sl * 4);
   long long part = (long long)layernorm_bwd_blocks((int)d.T) * 2 * d.D;
   part = std::max(part, (long long)colsum_blocks(d.B) * d.N * d.D);
   part = std::max(part, (long long)rmsnorm_bwd_blocks(d.B) * d.D);
-  part = std::max(part, (long long)transpose_colsum_blocks((int)d.T) * widest);   // bias-gradient partials of the dY transposes
-  part = std::max(part, (long long)colsum_bf16_blocks((int)d.T) * widest);
+  part = std::max(part, (long long)colsum_bf16_blocks((int)d.T) * widest);   // bias-gradient partials
   s.part = o; o += al128(part * 4);
   s.delta = o; o += al128((long long)d.B * d.H * d.N * 4);   // rowsum(dO o O) of the attention backward
   s.patches32 = o; o += al128((long long)d.B * d.P * d.pd * 4);
@@ -849,8 +829,6 @@ Bsb make_bsb(const Dims& d) {
 
 }  // namespace
 
-static int g_wgrad_bf16_transposes = 0;
-extern "C" void dgvit_set_wgrad_bf16_transposes(int on) { g_wgrad_bf16_transposes = on ? 1 : 0; }
 extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = tile; }
 extern "C" void dgvit_set_gemm_bf16_stamps(long long* stamps) { g_gemm_bf16_stamps = stamps; }
 
@@ -1025,7 +1003,7 @@ extern "C" int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* con
   for (int i = 0; i < np; ++i) DGVIT_CHECK_ARG(params[i] && grads[i], "parameter/gradient %d is null", i);
   const unsigned char* ws = (const unsigned char*)workspace;
   unsigned char* sc = (unsigned char*)scratch;
-  const int T = (int)d.T, Tp = s.Tp;
+  const int T = (int)d.T;
   float* dx = (float*)(sc + s.dxa);      // gradient of the residual stream entering the current op (fp32)
   float* dx2 = (float*)(sc + s.dxb);
   bf16_t* dxh = (bf16_t*)(sc + s.dxh);   // its bf16 copy: A operand of the data-gradient GEMMs, source of the transposed dY
@@ -1033,20 +1011,11 @@ extern "C" int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* con
   bf16_t* dqkv = (bf16_t*)(sc + s.dqkv);
   bf16_t* dao = (bf16_t*)(sc + s.dao);
   bf16_t* dh1 = (bf16_t*)(sc + s.dh1);
-  bf16_t* tA = (bf16_t*)(sc + s.tA);
-  bf16_t* tB = (bf16_t*)(sc + s.tB);
   float* slabs = (float*)(sc + s.slabs);
   float* part = (float*)(sc + s.part);
 
   // dW (no x ni) and optionally db (no) from dY (T x no, row stride ldy) and X (T x ni, row stride ldx)
-  // (the bias gradient = column sums of dY falls out of its transposition: per-row-block partials, then a fixed-order sum)
   auto wgrad = [&](const bf16_t* dY, int ldy, const bf16_t* X, int ldx, float* dW, float* db, int no, int ni) -> int {
-    if (g_wgrad_bf16_transposes) {   // A/B switch (tools): token-contiguous transposed copies + the NT kernel
-      TRY(transpose_bf16(dY, ldy, tA, T, no, Tp, db ? part : nullptr, st));
-      TRY(transpose_bf16(X, ldx, tB, T, ni, Tp, nullptr, st));
-      if (db) TRY(colpart_reduce(part, db, T, no, st));
-      return wgrad_bf16(tA, tB, dW, no, ni, Tp, slabs, s.slab_floats, st);
-    }
     if (db) TRY(colsum_bf16(dY, ldy, db, part, T, no, st));
     return wgrad_bf16_tn(dY, ldy, X, ldx, dW, no, ni, T, slabs, s.slab_floats, st);
   };
@@ -1131,26 +1100,18 @@ extern "C" int dgvit_gemm_bf16(int epilogue, const unsigned short* A, int lda, c
   return gemm_bf16(epilogue, p, (hipStream_t)stream);
 }
 extern "C" long long dgvit_wgrad_bf16_scratch_floats(int Mo, int Ko, int T) {
-  return wgrad_bf16_scratch(Mo, Ko, up8(T)) + (long long)std::max(transpose_colsum_blocks(T), colsum_bf16_blocks(T)) * Mo;
+  return wgrad_bf16_scratch(Mo, Ko, T) + (long long)colsum_bf16_blocks(T) * Mo;
 }
-extern "C" int dgvit_wgrad_bf16(const unsigned short* dY, const unsigned short* X, float* dW, float* db, unsigned short* tA,
-                                unsigned short* tB, float* slabs, long long slab_floats, int T, int Mo, int Ko, void* stream) {
+extern "C" int dgvit_wgrad_bf16(const unsigned short* dY, const unsigned short* X, float* dW, float* db, float* scratch,
+                                long long scratch_floats, int T, int Mo, int Ko, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  DGVIT_CHECK_ARG(dY && X && dW && tA && tB && T > 0 && Mo > 0 && Ko > 0 && Mo % 8 == 0 && Ko % 8 == 0, "dgvit_wgrad_bf16: bad arguments");
-  const int Tp = up8(T);
-  // slabs layout: [split-K slabs | bias-gradient partials]
-  const long long nsl = wgrad_bf16_scratch(Mo, Ko, Tp), npart = db ? (long long)std::max(transpose_colsum_blocks(T), colsum_bf16_blocks(T)) * Mo : 0;
-  if (slab_floats < nsl + npart) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "dgvit_wgrad_bf16: scratch %lld < %lld floats", slab_floats, nsl + npart);
-  DGVIT_CHECK_ARG(slabs || nsl + npart == 0, "dgvit_wgrad_bf16: null scratch");
-  float* part = slabs + nsl;
-  if (g_wgrad_bf16_transposes) {
-    TRY(transpose_bf16(dY, Mo, tA, T, Mo, Tp, db ? part : nullptr, st));
-    TRY(transpose_bf16(X, Ko, tB, T, Ko, Tp, nullptr, st));
-    if (db) TRY(colpart_reduce(part, db, T, Mo, st));
-    return wgrad_bf16(tA, tB, dW, Mo, Ko, Tp, slabs, nsl, st);
-  }
-  if (db) TRY(colsum_bf16(dY, Mo, db, part, T, Mo, st));
-  return wgrad_bf16_tn(dY, Mo, X, Ko, dW, Mo, Ko, T, slabs, nsl, st);
+  DGVIT_CHECK_ARG(dY && X && dW && T > 0 && Mo > 0 && Ko > 0 && Mo % 8 == 0 && Ko % 8 == 0, "dgvit_wgrad_bf16: bad arguments");
+  // scratch layout: [split-K slabs | bias-gradient partials]
+  const long long nsl = wgrad_bf16_scratch(Mo, Ko, T), npart = db ? (long long)colsum_bf16_blocks(T) * Mo : 0;
+  if (scratch_floats < nsl + npart) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "dgvit_wgrad_bf16: scratch %lld < %lld floats", scratch_floats, nsl + npart);
+  DGVIT_CHECK_ARG(scratch || nsl + npart == 0, "dgvit_wgrad_bf16: null scratch");
+  if (db) TRY(colsum_bf16(dY, Mo, db, scratch + nsl, T, Mo, st));
+  return wgrad_bf16_tn(dY, Mo, X, Ko, dW, Mo, Ko, T, scratch, nsl, st);
 }
 extern "C" int dgvit_layernorm_forward_bf16(const float* x, const float* gamma, const float* beta, unsigned short* y, float* mean,
                                             float* rstd, int rows, int D, void* stream) {

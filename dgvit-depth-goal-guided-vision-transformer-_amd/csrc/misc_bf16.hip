@@ -162,9 +162,9 @@ namespace {
 typedef bf16_t u16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4m __attribute__((ext_vector_type(4)));
 
-// dst (cols x ldd) = src (rows x cols, row stride ld)^T on 64 x 64 tiles; dst columns [rows, ldd) are zero filled
-// (ldd = rows rounded up to 8: the token dimension of the weight-gradient operands).  SRC = bf16_t or float (the
-// fp32 -> bf16 cast of a weight fused with its transposition).  cols % 8 == 0.
+// dst (cols x ldd) = src (rows x cols, row stride ld)^T on 64 x 64 tiles (ldd >= rows, multiple of 8; columns beyond `rows`
+// are zero filled).  SRC = float: the fp32 -> bf16 cast of a weight fused with its transposition (the B operands of the
+// data-gradient GEMMs); a bf16 source works the same way.  cols % 8 == 0.
 // A thread loads 8 columns of TWO adjacent rows and interleaves them in registers into 8 dwords {row r, row r + 1} of one
 // column each -- already transposed pairs -- so the LDS tile T[col][row pair] is written with dword stores (stride 33:
 // at most 2-way bank conflicts) and read back for the output rows with one ds_read_b128 per 16-byte store.
@@ -180,11 +180,9 @@ __device__ __forceinline__ u32x4m load8(const SRC* p) {
   }
 }
 
-// colpart (optional): colpart[blockIdx.y][col] = sum of the tile's 64 source rows of that column (fp32, fixed order) -- the
-// partial column sums of dY, i.e. the bias gradient once the row blocks are added up (reduce_slabs).
 template <typename SRC>
 __global__ void __launch_bounds__(256) transpose_bf16_kernel(const SRC* __restrict__ src, long long ld, bf16_t* __restrict__ dst,
-                                                             int rows, int cols, int ldd, float* __restrict__ colpart) {
+                                                             int rows, int cols, int ldd) {
   __shared__ unsigned tile[64][33];   // [column][row pair]
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
@@ -202,15 +200,6 @@ __global__ void __launch_bounds__(256) transpose_bf16_kernel(const SRC* __restri
     }
   }
   __syncthreads();
-  if (colpart && tid < 64 && c0 + tid < cols) {
-    float s = 0.f;
-#pragma unroll 8
-    for (int rp = 0; rp < 32; ++rp) {
-      const unsigned w = tile[tid][rp];
-      s += __builtin_bit_cast(float, w << 16) + __builtin_bit_cast(float, w & 0xFFFF0000u);
-    }
-    colpart[(long long)blockIdx.y * cols + c0 + tid] = s;
-  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int f = tid + i * 256, c = f >> 3, r8 = (f & 7) * 8;   // output row c0 + c, output columns r0 + r8 .. + 7
@@ -230,8 +219,6 @@ __global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const bf16_t* __rest
 }
 
 }  // namespace
-
-int transpose_colsum_blocks(int rows) { return (((rows + 7) & ~7) + 63) / 64; }
 
 // ---- column sums of a bf16 matrix (bias gradient db[n] = sum_t dY[t][n]): row-block partials, then colpart_reduce
 namespace {
@@ -294,10 +281,6 @@ static int colpart_reduce_n(const float* part, float* out, int nblk, int cols, h
   DGVIT_CHECK_LAUNCH("colpart_reduce");
   return DGVIT_OK;
 }
-// ... of the transpose_colsum_blocks(rows) partial rows written by transpose_bf16(colpart)
-int colpart_reduce(const float* part, float* out, int rows, int cols, hipStream_t st) {
-  return colpart_reduce_n(part, out, transpose_colsum_blocks(rows), cols, st);
-}
 
 // out[c] = sum_r src[r][c]; part: colsum_bf16_blocks(rows) * cols floats
 int colsum_bf16(const bf16_t* src, long long ld, float* out, float* part, int rows, int cols, hipStream_t st) {
@@ -310,23 +293,11 @@ int colsum_bf16(const bf16_t* src, long long ld, float* out, float* part, int ro
   return colpart_reduce_n(part, out, nblk, cols, st);
 }
 
-// colpart: null, or transpose_colsum_blocks(rows) * cols floats receiving the per-row-block column sums of src
-int transpose_bf16(const bf16_t* src, long long ld, bf16_t* dst, int rows, int cols, int ldd, float* colpart, hipStream_t st) {
-  DGVIT_CHECK_ARG(src && dst && rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0, "transpose_bf16: cols and ld must be multiples of 8");
-  DGVIT_CHECK_ARG(ldd >= rows && ldd % 8 == 0 && ldd - rows < 8, "transpose_bf16: ldd must be rows rounded up to a multiple of 8");
-  const int slot = profile_begin(PROF_OTHER, 0.0, st);
-  hipLaunchKernelGGL((transpose_bf16_kernel<bf16_t>), dim3((cols + 63) / 64, (ldd + 63) / 64), dim3(256), 0, st, src, ld, dst, rows, cols,
-                     ldd, colpart);
-  profile_end(slot, st);
-  DGVIT_CHECK_LAUNCH("transpose_bf16");
-  return DGVIT_OK;
-}
-
 int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int rows, int cols, hipStream_t st) {
   DGVIT_CHECK_ARG(src && dst && rows > 0 && cols > 0 && cols % 8 == 0 && rows % 8 == 0,
                   "transpose_cast_f32_bf16: rows and cols must be multiples of 8");
   hipLaunchKernelGGL((transpose_bf16_kernel<float>), dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, src, (long long)cols, dst,
-                     rows, cols, rows, (float*)nullptr);
+                     rows, cols, rows);
   DGVIT_CHECK_LAUNCH("transpose_cast_f32_bf16");
   return DGVIT_OK;
 }

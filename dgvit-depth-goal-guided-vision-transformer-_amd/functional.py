@@ -407,16 +407,13 @@ def op_wgrad_bf16(dy, x, want_bias=True):
     dy, x = _dev_bf16(dy, "dy"), _dev_bf16(x, "x")
     T, Mo = dy.shape
     Ko = x.shape[1]
-    T8 = (T + 7) // 8 * 8
     dev = dy.device
     dw = torch.empty(Mo, Ko, dtype=torch.float32, device=dev)
     db = torch.empty(Mo, dtype=torch.float32, device=dev) if want_bias else None
-    ta = torch.empty(Mo * T8, dtype=torch.bfloat16, device=dev)
-    tb = torch.empty(Ko * T8, dtype=torch.bfloat16, device=dev)
     ns = lib.dgvit_wgrad_bf16_scratch_floats(Mo, Ko, T)
-    slabs = torch.empty(max(ns, 4), dtype=torch.float32, device=dev)
+    scratch = torch.empty(max(ns, 4), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        rc = lib.dgvit_wgrad_bf16(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(ta), _ptr(tb), _ptr(slabs), ns, T, Mo, Ko, _stream())
+        rc = lib.dgvit_wgrad_bf16(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(scratch), ns, T, Mo, Ko, _stream())
     _lib.check(rc, "dgvit_wgrad_bf16")
     return (dw, db) if want_bias else dw
 

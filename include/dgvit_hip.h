@@ -228,11 +228,12 @@ int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* const* params,
                             void* scratch, long long scratch_bytes, int batch, float dropout_keep, unsigned long long dropout_seed,
                             const unsigned long long* dropout_seed_dev, void* stream);
 /* operator-level entry points of the bf16 kernels (parity tests, benches) */
-/* dW (Mo, Ko) fp32 = dY^T X and db (Mo, may be NULL) = column sums of dY, for dY (T, Mo) and X (T, Ko) bf16 (Mo, Ko % 8 == 0):
- * both are transposed into tA (Mo x T8) / tB (Ko x T8), T8 = T rounded up to 8, then multiplied split over tokens. */
+/* dW (Mo, Ko) fp32 = dY^T X and db (Mo, may be NULL) = column sums of dY, for dY (T, Mo) and X (T, Ko) bf16, token-major
+ * (Mo, Ko % 8 == 0): the TN layout of the ring GEMM (transposed LDS reads), split over tokens into fp32 slabs that are summed in
+ * a fixed order.  scratch: dgvit_wgrad_bf16_scratch_floats floats. */
 long long dgvit_wgrad_bf16_scratch_floats(int Mo, int Ko, int T);
-int dgvit_wgrad_bf16(const unsigned short* dY, const unsigned short* X, float* dW, float* db, unsigned short* tA, unsigned short* tB,
-                     float* slabs, long long slab_floats, int T, int Mo, int Ko, void* stream);
+int dgvit_wgrad_bf16(const unsigned short* dY, const unsigned short* X, float* dW, float* db, float* scratch,
+                     long long scratch_floats, int T, int Mo, int Ko, void* stream);
 int dgvit_cast_f32_bf16(const float* src, unsigned short* dst, long long n, void* stream);
 /* C = A B^T (+ epilogue), A (M,K) / B (N,K) bf16 with k contiguous, K, lda, ldb % 8 == 0, N, ldc % 4 == 0.
  * epilogue 0: C bf16 = acc + bias;  1: C bf16 = gelu(acc + bias);  2: C fp32 = acc + bias + res (fp32);
@@ -240,9 +241,6 @@ int dgvit_cast_f32_bf16(const float* src, unsigned short* dst, long long n, void
 int dgvit_gemm_bf16(int epilogue, const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, int M,
                     int N, int K, const float* bias, const float* res, int ldr, unsigned short* C2, int ldc2,
                     const unsigned short* aux, int ldaux, void* stream);
-/* A/B knob (default 0): 1 = weight gradients through token-contiguous transposed copies + the NT kernel instead of the
- * TN-layout kernel (transposed LDS reads, no copies) */
-void dgvit_set_wgrad_bf16_transposes(int on);
 /* test/bench knob: force the bf16 GEMM workgroup tile (0 = automatic; 256256, 256128, 128128) */
 void dgvit_set_gemm_bf16_tile(int tile);
 /* diagnostic (tools/bf16_stamps.py): non-NULL = the epilogue-0 ring GEMM runs its stamped build and writes, per workgroup,
