@@ -18,7 +18,6 @@ namespace {
 
 #define DGVIT_LOG2E 1.4426950408889634f
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ int vt_pos(int key) {

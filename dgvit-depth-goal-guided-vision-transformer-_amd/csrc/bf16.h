@@ -51,10 +51,8 @@ int layernorm_bwd_bf16(const bf16_t* dy, const float* x, const float* mean, cons
 int colsum_bf16_blocks(int rows);
 int colsum_bf16(const bf16_t* src, long long ld, float* out, float* part, int rows, int cols, hipStream_t st);
 int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int rows, int cols, hipStream_t st);
-int cast_bf16_f32(const bf16_t* src, float* dst, long long n, hipStream_t st);
 int attention_fwd_bf16(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N, int H, int dh, int nq, hipStream_t st);
 
 int attention_bwd_bf16(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout, const float* lse, bf16_t* dqkv, float* delta, int B,
                        int N, int H, int dh, hipStream_t st);
 
-__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }

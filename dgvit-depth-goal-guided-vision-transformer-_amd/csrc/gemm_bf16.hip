@@ -14,13 +14,13 @@
 //  * Epilogue: accumulators (column on the lane, rows in registers) are transposed through a wave-private slice of
 //    the now idle staging LDS so that global accesses are 16-byte (fp32) / 8-byte (bf16) row-contiguous pieces.
 //
-// gemm_bf16_ring_kernel (8 waves, 256-row tiles; the large GEMMs): measured, the kernel is bound by how many bytes
-// of LDS-DMA a CU keeps in flight (rate = bytes in flight / latency under load, ~2 us), not by instruction issue.  So
-// the k-tile is 32 deep (64-byte rows, chunks swizzled by ((row >> 2) & 3)) and the LDS is a ring of NS such tiles
-// with NS - 1 of them in flight.  Waves 0-3 and 4-7 (SIMD partners) run the same program one barrier interval apart
-// ("ping-pong"): per k-tile a wave LOADS its fragments and issues the DMA of tile t + NS - 1, passes a barrier,
-// COMPUTES 2 x MT x NTL MFMAs at raised priority, passes a barrier; every interval has one wave of each SIMD in its
-// MFMA segment and its partner in its load segment.
+// gemm_bf16_ring_kernel (8 waves, 256-row tiles; the large GEMMs): the k-tile is 32 deep (64-byte rows, chunks swizzled
+// by ((row >> 2) & 3)) and the LDS is a ring of NS such tiles with NS - 1 of them in flight.  Waves 0-3 and 4-7 (SIMD
+// partners) run the same program one barrier interval apart ("ping-pong"): per k-tile a wave LOADS its fragments and
+// issues the DMA of tile t + NS - 1, passes a barrier, COMPUTES 2 x MT x NTL MFMAs at raised priority, passes a
+// barrier; every interval has one wave of each SIMD in its MFMA segment and its partner in its load segment.
+// Measured: 1.4-1.7k cycles per k-tile against 512 MFMA-bound -- the load segment (12 fragment reads,
+// 4 DMA issues, two barriers) and the L2 -> LDS delivery of 32 KB per k-tile (21-23 B/clk/CU) set the pace, not MFMA issue.
 // gemm_bf16_kernel (4 waves, 128x128, BK = 64, two LDS buffers, one barrier per k-tile): small problems.
 #include "bf16.h"
 #include "kernels.h"

@@ -212,12 +212,6 @@ __global__ void __launch_bounds__(256) transpose_bf16_kernel(const SRC* __restri
   }
 }
 
-__global__ void __launch_bounds__(256) cast_bf16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long long n4) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n4) return;
-  reinterpret_cast<fx4*>(dst)[i] = __builtin_convertvector(reinterpret_cast<const bf16x4*>(src)[i], fx4);
-}
-
 }  // namespace
 
 // ---- column sums of a bf16 matrix (bias gradient db[n] = sum_t dY[t][n]): row-block partials, then colpart_reduce
@@ -299,13 +293,5 @@ int transpose_cast_f32_bf16(const float* src, bf16_t* dst, int rows, int cols, h
   hipLaunchKernelGGL((transpose_bf16_kernel<float>), dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, src, (long long)cols, dst,
                      rows, cols, rows);
   DGVIT_CHECK_LAUNCH("transpose_cast_f32_bf16");
-  return DGVIT_OK;
-}
-
-int cast_bf16_f32(const bf16_t* src, float* dst, long long n, hipStream_t st) {
-  DGVIT_CHECK_ARG(src && dst && n > 0 && n % 4 == 0, "cast_bf16_f32: n must be a positive multiple of 4");
-  const long long n4 = n / 4;
-  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, src, dst, n4);
-  DGVIT_CHECK_LAUNCH("cast_bf16_f32");
   return DGVIT_OK;
 }
