@@ -224,7 +224,17 @@ __global__ void __launch_bounds__(256) colsum_bf16_kernel(const bf16_t* __restri
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < cols) {
     const int r1 = min(rows, (int)(blockIdx.y + 1) * rows_per_blk);
-    for (int r = blockIdx.y * rows_per_blk + ty; r < r1; r += 4) {
+    int r = blockIdx.y * rows_per_blk + ty;
+    for (; r + 12 < r1; r += 16) {   // 4 rows in flight per thread
+      bf16x8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(src + (long long)(r + 4 * u) * ld + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += (float)v[u][j];
+    }
+    for (; r < r1; r += 4) {
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (long long)r * ld + c);
 #pragma unroll
       for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
@@ -239,7 +249,7 @@ __global__ void __launch_bounds__(256) colsum_bf16_kernel(const bf16_t* __restri
 }
 }  // namespace
 
-int colsum_bf16_blocks(int rows) { return rows < 4096 ? 1 : (rows < 65536 ? 64 : 256); }
+int colsum_bf16_blocks(int rows) { return rows < 4096 ? 1 : (rows < 16384 ? 64 : 256); }
 
 namespace {
 // out[c] = sum over the nblk row-block partials of column c; 64 columns x 16 row lanes per workgroup, fixed order
