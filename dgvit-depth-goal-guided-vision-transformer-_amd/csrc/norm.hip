@@ -214,14 +214,17 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, float* 
   return DGVIT_OK;
 }
 
-int layernorm_bwd_blocks(int T) { return T < 2048 ? (T + 3) / 4 : 512; }
+// workgroups (= partial rows of the dgamma / dbeta reduction) of the LayerNorm backward; also the scratch bound.  The row loop is
+// latency-bound, so the bf16 configuration (768-wide rows, 50k of them) runs 8 workgroups per CU; the fp32 path keeps 2.
+int layernorm_bwd_blocks(int T) { return T < 2048 ? (T + 3) / 4 : (T < 16384 ? 512 : 2048); }
+static int layernorm_bwd_blocks_f32(int T) { return T < 2048 ? (T + 3) / 4 : 512; }
 
 // partial must hold layernorm_bwd_blocks(T) * 2 * D floats; dgamma/dbeta are written (not accumulated)
 int layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
                   float* dx, float* dgamma, float* dbeta, float* partial, int T, int D, int rs, hipStream_t stream) {
   DGVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && partial, "layernorm_bwd: null pointer");
   DGVIT_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bwd: D=%d must be a multiple of 4, <= 1024", D);
-  const int nb = layernorm_bwd_blocks(T);
+  const int nb = layernorm_bwd_blocks_f32(T);
   const int nch = (D + 255) / 256;
 #define LNB(NCH)                                                                                                              \
   hipLaunchKernelGGL((layernorm_bwd_kernel<NCH, float>), dim3(nb), dim3(256), 0, stream, dy, x, mean, rstd, gamma, dres, dx, \
