@@ -121,3 +121,38 @@ def test_drop_in_module_names(amd):
     from dgvit_amd.got_sac_network import GoTPolicy, GoTQNetwork, DeterministicGoTPolicy, weights_init_
     assert GoT is amd.GoT and GoTPolicy is amd.GoTPolicy and GoTQNetwork is amd.GoTQNetwork
     assert DeterministicGoTPolicy is amd.DeterministicGoTPolicy and callable(weights_init_)
+
+
+def test_bf16_size_queries_and_host_switch_without_gpu(amd):
+    """bf16 configuration: arena / workspace / scratch sizes follow the documented layout; unsupported shapes are refused with a
+    message; GoT.set_compute_dtype is pure host state and leaves parameters and state_dict untouched."""
+    from dgvit_amd._lib import dgvit_config
+    lib = amd.load_library()
+    cfg = dgvit_config(224, 224, 16, 16, 768, 12, 12, 64, 3072)
+    D, I, M, L, pd, B, N = 768, 768, 3072, 12, 256, 64, 197
+    per_layer = 2 * (3 * I * D + D * I + M * D + D * M)          # the four GEMM weights and their transposes
+    assert lib.dgvit_got_bf16_weight_elems(ctypes.byref(cfg)) == D * pd + L * per_layer
+    T = B * N
+    infer = lib.dgvit_got_bf16_workspace_bytes(ctypes.byref(cfg), B, 0)
+    train = lib.dgvit_got_bf16_workspace_bytes(ctypes.byref(cfg), B, 1)
+    assert infer >= T * (2 * D * 2 + 3 * I * 2 + I * 2 + M * 2 + 3 * D * 4)          # one layer's operands + residual buffers
+    assert train >= L * T * (2 * D * 2 + 3 * I * 2 + I * 2 + 2 * M * 2 + 2 * D * 4)    # every layer keeps its activations
+    assert train > infer
+    assert lib.dgvit_got_bf16_backward_scratch_bytes(ctypes.byref(cfg), B) > T * (3 * I + M) * 2
+    assert lib.dgvit_wgrad_bf16_scratch_floats(768, 3072, T) >= 768 * 3072
+    bad = dgvit_config(84, 84, 12, 12, 256, 6, 8, 32, 2048)      # dim_head 32: fp32 path only
+    assert lib.dgvit_got_bf16_workspace_bytes(ctypes.byref(bad), 4, 0) < 0
+    assert b"dim_head" in lib.dgvit_last_error()
+    bad = dgvit_config(84, 84, 12, 12, 100, 2, 2, 64, 2048)      # dim not a multiple of 8
+    assert lib.dgvit_got_bf16_weight_elems(ctypes.byref(bad)) < 0
+    m = amd.GoT(image_size=(84, 84), patch_size=(12, 12), num_classes=2, dim=64, depth=1, heads=2, mlp_dim=64, channels=1)
+    keys = list(m.state_dict().keys())
+    assert m.compute_dtype == torch.float32
+    assert m.set_compute_dtype(torch.bfloat16) is m and m.compute_dtype == torch.bfloat16
+    assert list(m.state_dict().keys()) == keys and all(p.dtype == torch.float32 for p in m.parameters())
+    with pytest.raises(ValueError):
+        m.set_compute_dtype(torch.float16)
+    with pytest.raises(amd.DgvitError):                           # no CPU fallback in the bf16 configuration either
+        m(torch.rand(2, 84, 84), torch.rand(2, 64))
+    import copy
+    assert copy.deepcopy(m).compute_dtype == torch.bfloat16
