@@ -8,6 +8,7 @@ from .goalformer import GoT  # noqa: F401
 from .sac_networks import GoTPolicy, GoTQNetwork, DeterministicGoTPolicy, weights_init_  # noqa: F401
 from .cnn_networks import QNetwork, GaussianPolicy  # noqa: F401
 from . import functional  # noqa: F401
+from . import preprocess  # noqa: F401
 from .runtime import GraphedStep  # noqa: F401
 
 __all__ = ["GoT", "GoTPolicy", "GoTQNetwork", "DeterministicGoTPolicy", "QNetwork", "GaussianPolicy", "weights_init_", "functional", "GraphedStep", "DgvitError",

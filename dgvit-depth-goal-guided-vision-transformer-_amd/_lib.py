@@ -61,6 +61,12 @@ SIGNATURES = {
     "dgvit_cnn_forward": (_I, [_P, _TABLE, _P, _P, _LL, _P, _LL, _I, _I, _I, _P]),
     "dgvit_cnn_backward": (_I, [_P, _TABLE, _TABLE, _P, _P, _LL, _P, _LL, _I, _I, _I, _P]),
     "dgvit_gather_rows": (_I, [_P, _P, _P, _LL, _LL, _LL, _P]),
+    "dgvit_depth_preprocess_scratch_floats": (_LL, [_I, _I, _I]),
+    "dgvit_depth_to_state": (_I, [_P, _P, _F, _ULL, _P, _P, _LL, _I, _I, _I, _I, _I, _P]),
+    "dgvit_depth_normalize_u8": (_I, [_P, _P, _P, _LL, _I, _I, _I, _P]),
+    "dgvit_noise_clip": (_I, [_P, _P, _P, _LL, _F, _ULL, _P]),
+    "dgvit_gaussian_blur": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dgvit_resize_bilinear": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "dgvit_adam_step": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _F, _LL, _P, _P]),
     "dgvit_soft_update": (_I, [_P, _P, _LL, _F, _P]),
     "dgvit_got_bf16_weight_elems": (_LL, [_CFG]),

@@ -673,6 +673,48 @@ extern "C" int dgvit_gather_rows(const float* src, const long long* idx, float* 
   return gather_rows(src, idx, out, nsel, row_floats, nrows, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------------------------- SURVEY 8(f4)
+extern "C" long long dgvit_depth_preprocess_scratch_floats(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return -1;
+  return 2 * al4((long long)B * H * W) + al4(depth_normalize_scratch_floats(B));
+}
+extern "C" int dgvit_depth_normalize_u8(const float* depth, float* out, float* scratch, long long scratch_floats, int B, int H, int W,
+                                        void* stream) {
+  DGVIT_CHECK_ARG(scratch && scratch_floats >= depth_normalize_scratch_floats(B), "dgvit_depth_normalize_u8: scratch too small");
+  return depth_normalize_u8(depth, out, scratch, B, H, W, (hipStream_t)stream);
+}
+extern "C" int dgvit_noise_clip(const float* img, const float* noise, float* out, long long n, float noise_level, unsigned long long seed,
+                                void* stream) {
+  return noise_clip(img, noise, out, n, noise_level, seed, (hipStream_t)stream);
+}
+extern "C" int dgvit_gaussian_blur(const float* img, float* out, float* tmp, int B, int H, int W, int ksize, int row0, int row1,
+                                   void* stream) {
+  return gaussian_blur_band(img, out, tmp, B, H, W, ksize, row0, row1, (hipStream_t)stream);
+}
+extern "C" int dgvit_resize_bilinear(const float* img, float* out, int B, int Hs, int Ws, int Hd, int Wd, float scale, void* stream) {
+  return resize_bilinear(img, out, B, Hs, Ws, Hd, Wd, scale, (hipStream_t)stream);
+}
+// listener_callback (env_lab.py:420-434) + the resize of step() / reset() (:295-299): depth (B, H, W) -> state (B, out_h, out_w) in [0, 1]
+extern "C" int dgvit_depth_to_state(const float* depth, const float* noise, float noise_level, unsigned long long seed, float* state,
+                                    float* scratch, long long scratch_floats, int B, int H, int W, int out_h, int out_w, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DGVIT_CHECK_ARG(depth && state && scratch && B > 0 && H > 0 && W > 0 && out_h > 0 && out_w > 0, "dgvit_depth_to_state: bad arguments");
+  DGVIT_CHECK_ARG(((long long)H * W) % 4 == 0, "dgvit_depth_to_state: H * W must be a multiple of 4");
+  const long long n = (long long)B * H * W;
+  if (scratch_floats < dgvit_depth_preprocess_scratch_floats(B, H, W))
+    return dgvit_set_error(DGVIT_ERR_WORKSPACE, "dgvit_depth_to_state: scratch %lld < %lld floats", scratch_floats,
+                           dgvit_depth_preprocess_scratch_floats(B, H, W));
+  float* a = scratch;
+  float* b = scratch + al4(n);
+  float* part = b + al4(n);
+  TRY(depth_normalize_u8(depth, a, part, B, H, W, st));              // :424-426
+  TRY(noise_clip(a, noise, a, n, noise_level, seed, st));             // add_nose :86-88
+  TRY(gaussian_blur_band(a, a, b, B, H, W, 5, 0, H, st));             // add_nose :89   (b = horizontal pass, a = result)
+  const int bh = H / 5, y1 = H / 2 - bh / 2;                          // get_center_band :33-39
+  TRY(gaussian_blur_band(a, a, b, B, H, W, 11, y1, y1 + bh, st));     // blurring :69-76
+  return resize_bilinear(a, state, B, H, W, out_h, out_w, 1.0f / 255.0f, st);   // :295, :299
+}
+
 // ---------------------------------------------------------------------------------------------- bf16 configuration
 // BASELINE config 5 (224x224, ViT-Base variant, bf16): bf16 storage for GEMM operands (LayerNorm output, qkv,
 // attention output, MLP hidden, branch outputs, weights, and in backward their gradients), fp32 residual stream and its

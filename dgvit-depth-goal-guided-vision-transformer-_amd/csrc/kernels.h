@@ -28,4 +28,9 @@ int avgpool(const float*, float*, int, int, int, hipStream_t);
 int avgpool_bwd_relu(const float*, const float*, float*, int, int, int, hipStream_t);
 int gather_rows(const float*, const long long*, float*, long long, long long, long long, hipStream_t);
 int mean_bwd(const float*, float*, int, int, int, hipStream_t);
+int depth_normalize_u8(const float*, float*, float*, int, int, int, hipStream_t);
+long long depth_normalize_scratch_floats(int);
+int noise_clip(const float*, const float*, float*, long long, float, unsigned long long, hipStream_t);
+int gaussian_blur_band(const float*, float*, float*, int, int, int, int, int, int, hipStream_t);
+int resize_bilinear(const float*, float*, int, int, int, int, int, float, hipStream_t);
 extern int g_gemm_tile_hint;

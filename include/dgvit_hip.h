@@ -186,6 +186,23 @@ int dgvit_gather_rows(const float* src, const long long* idx, float* out, long l
                       long long nrows, void* stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * the depth-frame preprocessing in front of the path -- what env_lab.py does with OpenCV on the
+ * host for every camera message (listener_callback :420-434: cv2.normalize MINMAX -> uint8, add_nose :78-89 (N(0, 50) noise,
+ * clip, 5x5 Gaussian blur), blurring :69-76 (11x11 blur of the centre band)) and for every step (:295-299: cv2.resize to
+ * 160x128, / 255).  Frames are fp32 (B, H, W) on the device; noise == NULL draws N(0, noise_level) on the device (Philox).
+ * Parity against OpenCV is unpinned (cv2 is not installed in the build image; the oracle restates its published formulas).
+ * -------------------------------------------------------------------------------------------- */
+long long dgvit_depth_preprocess_scratch_floats(int B, int H, int W);
+int dgvit_depth_to_state(const float* depth, const float* noise, float noise_level, unsigned long long seed, float* state,
+                         float* scratch, long long scratch_floats, int B, int H, int W, int out_h, int out_w, void* stream);
+/* the stages (operator-level tests): scratch of dgvit_depth_normalize_u8 = 128 * B floats; tmp of dgvit_gaussian_blur = B*H*W floats,
+ * rows [row0, row1) are blurred (ksize 5 or 11, reflection inside the band), img may equal out */
+int dgvit_depth_normalize_u8(const float* depth, float* out, float* scratch, long long scratch_floats, int B, int H, int W, void* stream);
+int dgvit_noise_clip(const float* img, const float* noise, float* out, long long n, float noise_level, unsigned long long seed, void* stream);
+int dgvit_gaussian_blur(const float* img, float* out, float* tmp, int B, int H, int W, int ksize, int row0, int row1, void* stream);
+int dgvit_resize_bilinear(const float* img, float* out, int B, int Hs, int Ws, int Hd, int Wd, float scale, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
  * The step after the path: torch.optim.Adam.step over all tensors of a network
  * (DRL.py:401-403,412-414) and the Polyak target update target = target*(1-tau) + source*tau (utils.py:31-33),
  * each as ONE pass over flat fp32 buffers (n multiple of 4, 16-byte aligned; see dgvit_amd.optim).

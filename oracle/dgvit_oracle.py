@@ -477,3 +477,95 @@ def soft_update(target: Dict[str, Tensor], source: Dict[str, Tensor], tau: float
     """utils.py:31-33: target <- target*(1-tau) + source*tau."""
     for k in target:
         target[k].mul_(1.0 - tau).add_(source[k], alpha=tau)
+
+
+# --------------------------------------------------------------------------
+# SURVEY 8(f4): depth-frame preprocessing in front of the path (env_lab.py:420-434 listener_callback, :78-89 add_nose,
+# :69-76 blurring, :33-39 get_center_band, :295-299 / :348-349 resize + /255).
+# PARITY UNPINNED: the reference does this with OpenCV (cv2.normalize / GaussianBlur / resize), which is not installed
+# here and has no fixtures in the reference; the functions below restate OpenCV's published semantics for float32 images
+#   normalize(NORM_MINMAX, 0, 255): dst = src * a + b, a = 255 / (max - min) (0 when max - min <= DBL_EPSILON), b = -min * a
+#   .astype(np.uint8): truncation toward zero
+#   GaussianBlur(ksize, sigma 0): separable, BORDER_REFLECT_101; ksize 5 uses the fixed kernel [1, 4, 6, 4, 1] / 16, ksize 11
+#       sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8 = 2.0 with exp(-(i - c)^2 / (2 sigma^2)) normalised to sum 1
+#   resize(INTER_LINEAR): source coordinate (dst + 0.5) * scale - 0.5, index clamped to the image, weights (1 - f, f)
+# and are checked only for self-consistency (and, for the resize, against torch's independent bilinear interpolation).
+# --------------------------------------------------------------------------
+def f4_gaussian_kernel(ksize: int) -> np.ndarray:
+    if ksize == 5:
+        return np.array([0.0625, 0.25, 0.375, 0.25, 0.0625], np.float32)
+    sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    k = np.exp(-(x * x) / (2.0 * sigma * sigma))
+    return (k / k.sum()).astype(np.float32)
+
+
+def _reflect101(i: np.ndarray, n: int) -> np.ndarray:
+    if n == 1:
+        return np.zeros_like(i)
+    p = 2 * (n - 1)
+    i = np.abs(i) % p
+    return np.where(i >= n, p - i, i)
+
+
+def f4_gaussian_blur(img: np.ndarray, ksize: int) -> np.ndarray:
+    """cv2.GaussianBlur(img, (ksize, ksize), 0) on (..., H, W) float32 images."""
+    k = f4_gaussian_kernel(ksize)
+    r = ksize // 2
+    H, W = img.shape[-2:]
+    cols = _reflect101(np.arange(W)[:, None] + np.arange(-r, r + 1)[None, :], W)      # (W, ksize)
+    rows = _reflect101(np.arange(H)[:, None] + np.arange(-r, r + 1)[None, :], H)
+    tmp = (img[..., :, cols] * k).sum(-1, dtype=np.float32)                           # horizontal pass
+    return (tmp[..., rows, :] * k[None, :, None]).sum(-2, dtype=np.float32)           # vertical pass
+
+
+def f4_depth_to_uint8(img: np.ndarray) -> np.ndarray:
+    """listener_callback for float depth (env_lab.py:424-426): MINMAX-normalise to 0..255, truncate to integers (kept as float32)."""
+    img = img.astype(np.float32)
+    lo, hi = img.min(axis=(-2, -1), keepdims=True), img.max(axis=(-2, -1), keepdims=True)
+    d = hi.astype(np.float64) - lo
+    a = np.where(d > np.finfo(np.float64).eps, 255.0 / np.where(d > 0, d, 1.0), 0.0)
+    b = -lo * a
+    return np.trunc((img * a.astype(np.float32) + b.astype(np.float32)).astype(np.float32))
+
+
+def f4_add_nose(img: np.ndarray, noise: np.ndarray) -> np.ndarray:
+    """add_nose (env_lab.py:78-89) with the Gaussian draw supplied (noise = N(0, noise_level)): clip to 0..255, 5x5 blur."""
+    return f4_gaussian_blur(np.clip(img.astype(np.float32) + noise.astype(np.float32), 0, 255), 5)
+
+
+def f4_blurring(img: np.ndarray) -> np.ndarray:
+    """blurring (env_lab.py:69-76): 11x11 Gaussian blur of the horizontal centre band of height H // 5 (borders reflect inside the band)."""
+    H = img.shape[-2]
+    bh = H // 5
+    y1 = H // 2 - bh // 2
+    out = img.astype(np.float32).copy()
+    out[..., y1:y1 + bh, :] = f4_gaussian_blur(out[..., y1:y1 + bh, :], 11)
+    return out
+
+
+def f4_resize_to_state(img: np.ndarray, size=(128, 160)) -> np.ndarray:
+    """cv2.resize(img, (160, 128)) / 255 (env_lab.py:295,299): bilinear, half-pixel centres, clamped."""
+    Hd, Wd = size
+    Hs, Ws = img.shape[-2:]
+
+    def axis(nd, ns):
+        f = (np.arange(nd, dtype=np.float32) + 0.5) * np.float32(ns / nd) - 0.5
+        i0 = np.floor(f).astype(np.int64)
+        w = (f - i0).astype(np.float32)
+        w = np.where(i0 < 0, 0.0, w).astype(np.float32)
+        i0 = np.clip(i0, 0, ns - 1)
+        w = np.where(i0 >= ns - 1, 0.0, w).astype(np.float32)
+        return i0, np.minimum(i0 + 1, ns - 1), w
+
+    x0, x1, wx = axis(Wd, Ws)
+    y0, y1, wy = axis(Hd, Hs)
+    img = img.astype(np.float32)
+    h = img[..., :, x0] * (1 - wx) + img[..., :, x1] * wx
+    out = h[..., y0, :] * (1 - wy)[:, None] + h[..., y1, :] * wy[:, None]
+    return (out / np.float32(255)).astype(np.float32)
+
+
+def f4_pipeline(depth: np.ndarray, noise: np.ndarray, size=(128, 160)) -> np.ndarray:
+    """sensor depth frame -> encoder input: listener_callback (:420-434) then the resize of step() / reset() (:295-299)."""
+    return f4_resize_to_state(f4_blurring(f4_add_nose(f4_depth_to_uint8(depth), noise)), size)

@@ -178,3 +178,22 @@ def test_oracle_bf16_model_vs_reference(name):
     assert float((emu - ref32).abs().max()) < 1.5 * ref_gap + 2e-3
     assert float((emu - refbf).abs().max()) < 1.5 * ref_gap + 2e-3
     assert float((emu - ref32).abs().mean()) < 5e-3
+
+
+# ---------------------------------------------------------------- SURVEY 8(f4) preprocessing restatement (parity unpinned)
+def test_f4_oracle_self_consistency():
+    """The f4 functions restate OpenCV's published formulas (cv2 is not installed: PARITY UNPINNED); checked here: invariants and the
+    bilinear resize against torch's independent implementation of the same half-pixel-centre formula."""
+    rs = np.random.RandomState(0)
+    d = rs.uniform(0.3, 9.0, (2, 44, 64)).astype(np.float32)
+    u = O.f4_depth_to_uint8(d)
+    assert u.min() == 0 and u.max() in (254, 255) and (u == np.trunc(u)).all()
+    c = np.full((1, 40, 60), 137, np.float32)
+    assert np.allclose(O.f4_gaussian_blur(c, 5), 137) and np.allclose(O.f4_gaussian_blur(c, 11), 137, atol=1e-4)
+    assert abs(float(O.f4_gaussian_kernel(11).sum()) - 1) < 1e-6 and np.array_equal(O.f4_gaussian_kernel(5) * 16, [1, 4, 6, 4, 1])
+    noise = (rs.standard_normal(d.shape) * 50).astype(np.float32)
+    b = O.f4_blurring(O.f4_add_nose(u, noise))
+    s = O.f4_resize_to_state(b)
+    t = torch.nn.functional.interpolate(torch.from_numpy(b)[:, None], size=(128, 160), mode="bilinear", align_corners=False)[:, 0] / 255
+    np.testing.assert_allclose(s, t.numpy(), atol=1e-6)
+    assert O.f4_pipeline(d, noise).shape == (2, 128, 160)
