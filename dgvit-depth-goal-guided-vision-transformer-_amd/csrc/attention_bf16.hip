@@ -25,14 +25,39 @@ __device__ __forceinline__ int vt_pos(int key) {
   return (key & ~15) | (((w >> 2) & 1) << 3) | ((w >> 3) << 2) | (w & 3);
 }
 
+// transposed fragment of a row-major [token][64] image (128-byte rows, chunk c of row r stored at c ^ (((r >> 1) & 1) << 2)):
+// A[row = feature 32 dt + (lane & 31)][k = the 8 tokens 16 s + 8 (j >> 2) + 4 h + (j & 3)] of token tile `t0` -- the order
+// in which a 32x32 accumulator's registers 8s .. 8s+7 present their rows (see the header).  Two ds_read_b64_tr_b16: per
+// 16-lane group the hardware reads 4 tokens x 16 features and hands lane i feature i; the swizzle puts the four token rows
+// on four different 64-byte bank groups.  EXEC must be all ones (uniform control flow only around this).
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* img, int t0, int dt, int s, int lane) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const int w = lane & 15, q = w >> 2, p = w & 3, cb = (lane >> 4) & 1, h = lane >> 5;
+  const int c = ((dt ^ ((q >> 1) & 1)) << 2) | (2 * cb + (p >> 1));
+  const unsigned char* a = img + (t0 + 16 * s + 4 * h + q) * 128 + c * 16 + (p & 1) * 8;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 8 * 128));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// rows [0, N) of a 64-wide per-head column block -> that image (rows >= N zero)
+template <int NTHR>
+__device__ __forceinline__ void stage_rows_tr(unsigned char* img, const bf16_t* src, long long ld, int N, int NP, int tid) {
+  for (int f = tid; f < NP * 8; f += NTHR) {
+    const int row = f >> 3, pc = f & 7, c = pc ^ (((row >> 1) & 1) << 2);
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    if (row < N) v = *reinterpret_cast<const u32x4_t*>(src + row * ld + c * 8);
+    *reinterpret_cast<u32x4_t*>(img + row * 128 + pc * 16) = v;
+  }
+}
+
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                 float* __restrict__ lse, int N, int H, float scale, int nq) {
   constexpr int DH = 64, NTHR = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int nkt = (N + 31) / 32, NP = nkt * 32, VS = NP + 8;   // VS: Vt row stride in elements
+  const int nkt = (N + 31) / 32, NP = nkt * 32;
   unsigned char* Ks = smem;
-  bf16_t* Vt = reinterpret_cast<bf16_t*>(smem + NP * 128);
+  unsigned char* Vs = smem + NP * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int b = blockIdx.x / H, hd = blockIdx.x % H;
@@ -41,25 +66,14 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_bf16_kernel(const bf16_t* __
   const bf16_t* base = qkv + (long long)b * N * ld + hd * DH;
   const float sc = scale * DGVIT_LOG2E;
 
-  // ---- stage K (swizzled rows) and V (transposed), zero padding keys >= N ------------------------------------
+  // ---- stage K (row image for ds_read_b128) and V (row image for transposed reads), zero padding keys >= N ----
   for (int f = tid; f < NP * 8; f += NTHR) {
     const int row = f >> 3, pc = f & 7, c = pc ^ ((row >> 1) & 7);
     u32x4_t v = {0u, 0u, 0u, 0u};
     if (row < N) v = *reinterpret_cast<const u32x4_t*>(base + I + row * ld + c * 8);
     *reinterpret_cast<u32x4_t*>(Ks + row * 128 + pc * 16) = v;
   }
-  for (int f = tid; f < (NP / 2) * 8; f += NTHR) {
-    const int kp = f >> 3, dc = f & 7, key = kp * 2;   // keys (key, key + 1) are adjacent in the permuted order
-    u32x4_t v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
-    if (key < N) v0 = *reinterpret_cast<const u32x4_t*>(base + 2 * I + key * ld + dc * 8);
-    if (key + 1 < N) v1 = *reinterpret_cast<const u32x4_t*>(base + 2 * I + (key + 1) * ld + dc * 8);
-    unsigned* dst = reinterpret_cast<unsigned*>(Vt + (dc * 8) * VS + vt_pos(key));
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      dst[(2 * i) * (VS / 2)] = (v0[i] & 0xFFFFu) | (v1[i] << 16);
-      dst[(2 * i + 1) * (VS / 2)] = (v0[i] >> 16) | (v1[i] & 0xFFFF0000u);
-    }
-  }
+  stage_rows_tr<NTHR>(Vs, base + 2 * I, ld, N, NP, tid);
   __syncthreads();
 
   const unsigned fsw = (unsigned)((li >> 1) & 7);
@@ -125,10 +139,7 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_bf16_kernel(const bf16_t* __
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(Vt + (dt * 32 + li) * VS + kt * 32 + 16 * s + 8 * h);
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[s], o[dt], 0, 0, 0);
-        }
+        for (int s = 0; s < 2; ++s) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vs, kt * 32, dt, s, lane), pf[s], o[dt], 0, 0, 0);
     }
     if (q < nq) {
       const float inv = 1.f / l;
@@ -365,7 +376,7 @@ int attention_fwd_bf16(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N,
   DGVIT_CHECK_ARG(N >= 1 && N <= 224, "attention_bf16: tokens N=%d outside [1, 224]", N);
   DGVIT_CHECK_ARG(nq >= 1 && nq <= N, "attention_bf16: bad query limit");
   const int NP = (N + 31) / 32 * 32;
-  const size_t lds = (size_t)NP * 128 + (size_t)64 * (NP + 8) * 2;
+  const size_t lds = (size_t)2 * NP * 128;
   const float scale = 1.0f / sqrtf((float)dh);
   const double flops = 4.0 * (double)nq * N * dh * H * B;
   const int slot = profile_begin(PROF_ATTN_FWD, flops, st);
