@@ -5,12 +5,15 @@
 // cross-half exchange and the probability tile, converted to bf16 pairwise, IS the B operand of O^T = V^T P^T
 // (registers 8s..8s+7 form k-step s; element j of lane half h is key 16 s + 8 (j >> 2) + 4 h + (j & 3)).
 //
-// LDS images:
-//   K  [NP][64] bf16, 128-byte rows, 16-byte chunks XOR-swizzled by ((key >> 1) & 7)  -> conflict-free ds_read_b128
-//   Vt [64][NP + 8] bf16: V transposed at staging time (the contraction index of P V is the key, so V must be
-//      k-contiguous per feature row); inside each 16-key group keys are stored at position 8*((k>>2)&1) + 4*(k>>3) + (k&3)
-//      so that the eight keys a lane needs for one k-step are 16 contiguous bytes.  Row stride (2 NP + 16) bytes =
-//      16 x odd: the 16 lanes of a ds_read_b128 group hit 16 distinct bank slots.
+// LDS images (64 features = 128-byte rows per token):
+//   row image for ds_read_b128 fragments (K in forward; K, V, Q, dO rows in backward): 16-byte chunks XOR-swizzled by
+//      ((token >> 1) & 7) -> conflict-free
+//   forward V: row image read TRANSPOSED with ds_read_b64_tr_b16 (tr_frag): the contraction index of P V is the key, so a
+//      lane needs 4 + 4 consecutive keys of its own feature -- the hardware transposes 4 x 16 blocks on the fly
+//   backward K / Q / dO transposed images [64][NP + 8] built at staging time (stage_transposed): inside each 16-token group
+//      tokens are stored at position 8*((k>>2)&1) + 4*(k>>3) + (k&3) so that the eight tokens a lane needs for one k-step are
+//      16 contiguous bytes; row stride (2 NP + 16) bytes = 16 x odd: the 16 lanes of a ds_read_b128 group hit 16 distinct
+//      bank slots.  (Both forms measured equal in the forward kernel: it is bound by staging latency and softmax VALU.)
 #include "bf16.h"
 #include "kernels.h"
 
