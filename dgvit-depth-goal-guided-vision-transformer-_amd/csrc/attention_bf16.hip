@@ -70,13 +70,34 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_bf16_kernel(const bf16_t* __
   const float sc = scale * DGVIT_LOG2E;
 
   // ---- stage K (row image for ds_read_b128) and V (row image for transposed reads), zero padding keys >= N ----
-  for (int f = tid; f < NP * 8; f += NTHR) {
-    const int row = f >> 3, pc = f & 7, c = pc ^ ((row >> 1) & 7);
-    u32x4_t v = {0u, 0u, 0u, 0u};
-    if (row < N) v = *reinterpret_cast<const u32x4_t*>(base + I + row * ld + c * 8);
-    *reinterpret_cast<u32x4_t*>(Ks + row * 128 + pc * 16) = v;
+  // all of a thread's 16-byte loads are requested before the first LDS write (a load-store-load-store loop would serialise
+  // one memory round trip per chunk)
+  {
+    constexpr int CH = 4;   // chunks per thread, image and trip: NP * 8 <= CH * NTHR for every supported N when NTHR = 512
+    for (int f0 = tid; f0 < NP * 8; f0 += CH * NTHR) {
+      u32x4_t kv[CH], vv[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int f = f0 + j * NTHR, row = f >> 3, pc = f & 7;
+        const bool ok = f < NP * 8 && row < N;
+        const int rr = ok ? row : 0;
+        kv[j] = *reinterpret_cast<const u32x4_t*>(base + I + rr * ld + (pc ^ ((row >> 1) & 7)) * 8);
+        vv[j] = *reinterpret_cast<const u32x4_t*>(base + 2 * I + rr * ld + (pc ^ (((row >> 1) & 1) << 2)) * 8);
+        if (!ok) {
+          kv[j] = u32x4_t{0u, 0u, 0u, 0u};
+          vv[j] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int f = f0 + j * NTHR, row = f >> 3, pc = f & 7;
+        if (f < NP * 8) {
+          *reinterpret_cast<u32x4_t*>(Ks + row * 128 + pc * 16) = kv[j];
+          *reinterpret_cast<u32x4_t*>(Vs + row * 128 + pc * 16) = vv[j];
+        }
+      }
+    }
   }
-  stage_rows_tr<NTHR>(Vs, base + 2 * I, ld, N, NP, tid);
   __syncthreads();
 
   const unsigned fsw = (unsigned)((li >> 1) & 7);
@@ -169,29 +190,55 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_bf16_kernel(const bf16_t* __
 //     P = exp2(Q K^T sc - lse), dP = dO V^T, dS = P o (dP - delta) * scale, dV^T += dO^T P, dK^T += Q^T dS
 // Every product keeps the "accumulator registers are the next MFMA's B operand" orientation of the forward kernel.
 
-// rows [0, N) of a 64-wide per-head column block -> LDS row image [NP][128 B], chunks swizzled by ((row >> 1) & 7)
+// rows [0, N) of a 64-wide per-head column block -> LDS row image [NP][128 B], chunks swizzled by ((row >> 1) & 7).
+// (staging loops request all of a thread's 16-byte loads before the first LDS write: a load-store-load-store loop would
+//  serialise one memory round trip per chunk)
 template <int NTHR>
 __device__ __forceinline__ void stage_rows(unsigned char* img, const bf16_t* src, long long ld, int N, int NP, int tid) {
-  for (int f = tid; f < NP * 8; f += NTHR) {
-    const int row = f >> 3, pc = f & 7, c = pc ^ ((row >> 1) & 7);
-    u32x4_t v = {0u, 0u, 0u, 0u};
-    if (row < N) v = *reinterpret_cast<const u32x4_t*>(src + row * ld + c * 8);
-    *reinterpret_cast<u32x4_t*>(img + row * 128 + pc * 16) = v;
+  constexpr int CH = 4;
+  for (int f0 = tid; f0 < NP * 8; f0 += CH * NTHR) {
+    u32x4_t v[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int f = f0 + j * NTHR, row = f >> 3, pc = f & 7;
+      const bool ok = f < NP * 8 && row < N;
+      v[j] = *reinterpret_cast<const u32x4_t*>(src + (ok ? row : 0) * ld + (pc ^ ((row >> 1) & 7)) * 8);
+      if (!ok) v[j] = u32x4_t{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int f = f0 + j * NTHR;
+      if (f < NP * 8) *reinterpret_cast<u32x4_t*>(img + (f >> 3) * 128 + (f & 7) * 16) = v[j];
+    }
   }
 }
 // the same block transposed: img[d][vt_pos(row)], row stride VS elements (see the header of this file)
 template <int NTHR>
 __device__ __forceinline__ void stage_transposed(bf16_t* img, const bf16_t* src, long long ld, int N, int NP, int VS, int tid) {
-  for (int f = tid; f < (NP / 2) * 8; f += NTHR) {
-    const int kp = f >> 3, dc = f & 7, row = kp * 2;
-    u32x4_t v0 = {0u, 0u, 0u, 0u}, v1 = {0u, 0u, 0u, 0u};
-    if (row < N) v0 = *reinterpret_cast<const u32x4_t*>(src + row * ld + dc * 8);
-    if (row + 1 < N) v1 = *reinterpret_cast<const u32x4_t*>(src + (row + 1) * ld + dc * 8);
-    unsigned* dst = reinterpret_cast<unsigned*>(img + (dc * 8) * VS + vt_pos(row));
+  constexpr int CH = 2;
+  const int total = (NP / 2) * 8;
+  for (int f0 = tid; f0 < total; f0 += CH * NTHR) {
+    u32x4_t v0[CH], v1[CH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      dst[(2 * i) * (VS / 2)] = (v0[i] & 0xFFFFu) | (v1[i] << 16);
-      dst[(2 * i + 1) * (VS / 2)] = (v0[i] >> 16) | (v1[i] & 0xFFFF0000u);
+    for (int j = 0; j < CH; ++j) {
+      const int f = f0 + j * NTHR, row = (f >> 3) * 2, dc = f & 7;
+      const bool ok0 = f < total && row < N, ok1 = f < total && row + 1 < N;
+      v0[j] = *reinterpret_cast<const u32x4_t*>(src + (ok0 ? row : 0) * ld + dc * 8);
+      v1[j] = *reinterpret_cast<const u32x4_t*>(src + (ok1 ? row + 1 : 0) * ld + dc * 8);
+      if (!ok0) v0[j] = u32x4_t{0u, 0u, 0u, 0u};
+      if (!ok1) v1[j] = u32x4_t{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int f = f0 + j * NTHR, row = (f >> 3) * 2, dc = f & 7;
+      if (f < total) {
+        unsigned* dst = reinterpret_cast<unsigned*>(img + (dc * 8) * VS + vt_pos(row));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          dst[(2 * i) * (VS / 2)] = (v0[j][i] & 0xFFFFu) | (v1[j][i] << 16);
+          dst[(2 * i + 1) * (VS / 2)] = (v0[j][i] >> 16) | (v1[j][i] & 0xFFFF0000u);
+        }
+      }
     }
   }
 }
