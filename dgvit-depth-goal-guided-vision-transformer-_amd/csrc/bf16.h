@@ -37,6 +37,7 @@ struct GemmBf16Params {
 
 int gemm_bf16(int epi, const GemmBf16Params& p, hipStream_t st);
 extern int g_gemm_bf16_tile_hint;
+extern int g_gemm_bf16_m16;
 extern long long* g_gemm_bf16_stamps;
 
 int cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t st);

@@ -872,6 +872,7 @@ Bsb make_bsb(const Dims& d) {
 }  // namespace
 
 extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = tile; }
+extern "C" void dgvit_set_gemm_bf16_mfma16(int on) { g_gemm_bf16_m16 = on ? 1 : 0; }
 extern "C" void dgvit_set_gemm_bf16_stamps(long long* stamps) { g_gemm_bf16_stamps = stamps; }
 
 extern "C" long long dgvit_got_bf16_weight_elems(const dgvit_config* cfg) {

@@ -26,6 +26,7 @@
 #include "kernels.h"
 
 int g_gemm_bf16_tile_hint = 0;
+int g_gemm_bf16_m16 = 1;   // the ring kernel issues v_mfma_f32_16x16x32_bf16 (default; 0 = 32x32x16: A/B knob dgvit_set_gemm_bf16_mfma16)
 long long* g_gemm_bf16_stamps = nullptr;   // diagnostic: see STAMP in gemm_bf16_ring_kernel
 
 namespace {
@@ -232,9 +233,16 @@ typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 // two `ds_read_b64_tr_b16`: per 16-lane group the hardware reads a 4 (k) x 16 (m) block and hands lane i column i, so a
 // lane gets 4 consecutive k of its own m -- exactly the MFMA operand order.  The swizzle puts the block's 4 rows on the
 // four 64-byte bank groups: a 32-lane half (two blocks) touches every bank once.
-template <class T, int EPI, bool STAMP = false, bool TN = false>
+// M16: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same cycles per FLOP, same LDS bytes; the kernel runs under the chip's
+// power limit on random data -- all-zero operands are 11-44 % faster -- and the 16x16 shape draws less: MI355X_MICROARCH.md,
+// 'DVFS give-back' item 7).  A k-tile is exactly one 32-deep MFMA step: lane l holds row l & 15, k = 8 (l >> 4) .. + 7, i.e.
+// chunk l >> 4 of the 64-byte row (chunk c of row r stored at c ^ {0,2,3,1}[(r >> 2) & 3]: conflict-free for this read
+// pattern); TN: 16-lane group g transposes k-rows 8 g .. 8 g + 7 of 16 columns (chunk swizzle ((r & 3) << 2) | (((r >> 3) & 1) << 1)).
+// Accumulators: 16x16 tiles of 4 registers, column l & 15, row 4 (l >> 4) + register.
+template <class T, int EPI, bool STAMP = false, bool TN = false, bool M16 = false>
 __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Params p, int ntiles, long long* stamps = nullptr) {
   static_assert(!TN || (T::BM == 256 && T::BN == 256), "the TN layout is built for the 256 x 256 tile");
+  constexpr int MT16 = T::WTM / 16, NT16 = T::WTN / 16;
   constexpr int BM = T::BM, BN = T::BN, MT = T::MT, NTL = T::NTL, WTM = T::WTM, WTN = T::WTN;
   using R = Ring<T, EPI>;
   constexpr int NS = R::NS, D = R::D;
@@ -266,7 +274,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   // (TN: one instruction fills 2 k-rows x 512 bytes: lane -> row lane >> 5 of the pair, physical chunk lane & 31 holding
   //  logical chunk (lane & 31) ^ ((row & 3) << 2); wave w owns the row pairs w and w + 8, so row & 3 = 2 (w & 1) + (lane >> 5))
   const int srow = TN ? (lane >> 5) : (lane >> 2);
-  const int sc = TN ? ((lane & 31) ^ (((2 * (wave & 1) + (lane >> 5)) & 3) << 2)) : ((lane & 3) ^ ((lane >> 4) & 3));
+  constexpr unsigned STAB = 0x1320u;   // {0, 2, 3, 1}[i] = (STAB >> 4 i) & 3: chunk swizzle of the 16x16x32 row reads
+  const int sc = TN ? ((lane & 31) ^ ((((2 * (wave & 1) + (lane >> 5)) & 3) << 2) | (M16 ? (((wave >> 2) & 1) << 1) : 0)))
+                    : ((lane & 3) ^ (M16 ? (int)((STAB >> (4 * ((lane >> 4) & 3))) & 3u) : ((lane >> 4) & 3)));
   const unsigned offA = ((unsigned)(wave * (TN ? 2 : 16) + srow) * (unsigned)p.lda + sc * 8u) * 2u;
   const unsigned offB = ((unsigned)(wave * (TN ? 2 : 16) + srow) * (unsigned)p.ldb + sc * 8u) * 2u;
   // distance between a wave's DMA instructions of one k-tile: NT 128 tile rows, TN 16 k-rows
@@ -352,6 +362,28 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
 #pragma unroll
     for (int j = 0; j < NTL; ++j) tb[j] = tr_base(16384u, (unsigned)(wc * (WTN / 32) + j));
   }
+  // M16 fragment bases
+  const unsigned l15 = (unsigned)(lane & 15), g16 = (unsigned)(lane >> 4);
+  const unsigned a16 = (unsigned)(wr * WTM + l15) * 64u + ((g16 ^ ((STAB >> (4 * (l15 >> 2))) & 3u)) * 16u);
+  const unsigned b16 = (unsigned)(BM + wc * WTN + l15) * 64u + ((g16 ^ ((STAB >> (4 * (l15 >> 2))) & 3u)) * 16u);
+  // TN + M16: group g16 reads k-rows 8 g16 + 4 u + (0..3) of the 16 columns of tile X16; lane 4q + p addresses row q, columns 4p..
+  auto tr_base16 = [&](unsigned region, unsigned X16) {
+    return region + (8u * g16 + tq) * 512u + ((((((X16 >> 1) ^ tq) << 2) | ((X16 & 1u) << 1) | (tp >> 1)) ^ ((g16 & 1u) << 1)) * 16u) +
+           (tp & 1u) * 8u;
+  };
+  unsigned ta16[(TN && M16) ? MT16 : 1], tb16[(TN && M16) ? NT16 : 1];
+  if constexpr (TN && M16) {
+#pragma unroll
+    for (int i = 0; i < MT16; ++i) ta16[i] = tr_base16(0u, (unsigned)(wr * MT16 + i));
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) tb16[j] = tr_base16(16384u, (unsigned)(wc * NT16 + j));
+  }
+  auto tr_frag16 = [&](const unsigned char* sb, unsigned base) {
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sb + base));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sb + base + 2048));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
   auto tr_frag = [&](const unsigned char* sb, unsigned base, int s) {
     typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
     const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(sb + base + s * 8192));
@@ -362,8 +394,10 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   constexpr int LPR = WTN / 4, RPI = 64 / LPR;   // lanes per output row piece, rows per staging read
   const int erow = lane / LPR, ecol = (lane % LPR) * 4;
 
-  f32x16 acc[MT][NTL];
+  f32x16 acc[M16 ? 1 : MT][M16 ? 1 : NTL];
+  f32x4 acc4[M16 ? MT16 : 1][M16 ? NT16 : 1];
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   int ctile = blockIdx.x, ct = 0, cslot = 0, since_epi = D, ntile_done = 0;
   int cnkt = (slice_len(xcd_chunk(ctile, ntiles) % S) + 31) / 32;
   long long st0 = 0;
@@ -377,19 +411,32 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   if (grp == 1) __builtin_amdgcn_s_barrier();
   while (ctile < ntiles) {
     const unsigned char* sb = smem + cslot * R::SLOT;
-    bf16x8 af[2][MT], bf[2][NTL];
+    bf16x8 af[M16 ? 1 : 2][M16 ? MT16 : MT], bf[M16 ? 1 : 2][M16 ? NT16 : NTL];
+    if constexpr (M16) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if constexpr (TN) {
+      for (int i = 0; i < MT16; ++i) {
+        if constexpr (TN) af[0][i] = tr_frag16(sb, ta16[i]);
+        else af[0][i] = *reinterpret_cast<const bf16x8*>(sb + a16 + i * 1024);
+      }
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[s][i] = tr_frag(sb, ta[i], s);
+      for (int j = 0; j < NT16; ++j) {
+        if constexpr (TN) bf[0][j] = tr_frag16(sb, tb16[j]);
+        else bf[0][j] = *reinterpret_cast<const bf16x8*>(sb + b16 + j * 1024);
+      }
+    } else {
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) bf[s][j] = tr_frag(sb, tb[j], s);
-      } else {
+      for (int s = 0; s < 2; ++s) {
+        if constexpr (TN) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(sb + (a_l0 ^ (s * 32u)) + i * 2048);
+          for (int i = 0; i < MT; ++i) af[s][i] = tr_frag(sb, ta[i], s);
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) bf[s][j] = *reinterpret_cast<const bf16x8*>(sb + (b_l0 ^ (s * 32u)) + j * 2048);
+          for (int j = 0; j < NTL; ++j) bf[s][j] = tr_frag(sb, tb[j], s);
+        } else {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[s][i] = *reinterpret_cast<const bf16x8*>(sb + (a_l0 ^ (s * 32u)) + i * 2048);
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) bf[s][j] = *reinterpret_cast<const bf16x8*>(sb + (b_l0 ^ (s * 32u)) + j * 2048);
+        }
       }
     }
     issue_next();
@@ -400,21 +447,35 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    if (ct == 0) {   // first k-tile of an output tile: accumulate onto zero (no 128-register clear)
+    if constexpr (M16) {
+      if (ct == 0) {   // first k-tile of an output tile: accumulate onto zero
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT16; ++i)
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], zero16, 0, 0, 0);
+          for (int j = 0; j < NT16; ++j) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0][j], zero4, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT16; ++i)
+#pragma unroll
+          for (int j = 0; j < NT16; ++j) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0][j], acc4[i][j], 0, 0, 0);
+      }
     } else {
+      if (ct == 0) {   // first k-tile of an output tile: accumulate onto zero (no 128-register clear)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], zero16, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NTL; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][j], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -469,10 +530,17 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
         for (int half = 0; half < 2; ++half) {
           if (EPI == BEPI_DGELU_BF16 && half == 0 && i + 1 < MT) aux_fetch(i + 1, auxv[EPI == BEPI_DGELU_BF16 ? i + 1 : 0]);
           __builtin_amdgcn_wave_barrier();
+          if constexpr (M16) {   // 16-row block 2 i + half: rows 4 (lane >> 4) + r, columns 16 j + (lane & 15)
 #pragma unroll
-          for (int j = 0; j < NTL; ++j)
+            for (int j = 0; j < NT16; ++j)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) es[((r & 3) + 8 * (r >> 2) + 4 * h) * WTN + j * 32 + li] = acc[i][j][8 * half + r];
+              for (int r = 0; r < 4; ++r) es[(4 * (lane >> 4) + r) * WTN + j * 16 + (lane & 15)] = acc4[2 * i + half][j][r];
+          } else {
+#pragma unroll
+            for (int j = 0; j < NTL; ++j)
+#pragma unroll
+              for (int r = 0; r < 8; ++r) es[((r & 3) + 8 * (r >> 2) + 4 * h) * WTN + j * 32 + li] = acc[i][j][8 * half + r];
+          }
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int q = 0; q < 16 / RPI; ++q) {
@@ -581,7 +649,16 @@ int launch(const GemmBf16Params& p, hipStream_t st) {
           tn_attr = true;
         }
         const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, st);
-        hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI, false, true>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, (long long*)nullptr);
+        if (g_gemm_bf16_m16) {
+          static bool a16 = false;
+          if (!a16 && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<T, EPI, false, true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit");
+          a16 = true;
+          hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI, false, true, true>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, (long long*)nullptr);
+        } else {
+          hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI, false, true>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, (long long*)nullptr);
+        }
         profile_end(slot, st);
         DGVIT_CHECK_LAUNCH("gemm_bf16_ring_kernel(TN)");
         return DGVIT_OK;
@@ -589,7 +666,16 @@ int launch(const GemmBf16Params& p, hipStream_t st) {
     }
     DGVIT_CHECK_ARG(!p.tn, "gemm_bf16: the TN layout needs the plain fp32 epilogue and the 256 x 256 tile");
     const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, st);
-    hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, (long long*)nullptr);
+    if (g_gemm_bf16_m16) {
+      static bool a16 = false;
+      if (!a16 && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<T, EPI, false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit");
+      a16 = true;
+      hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI, false, false, true>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, (long long*)nullptr);
+    } else {
+      hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, (long long*)nullptr);
+    }
     profile_end(slot, st);
   } else {
     DGVIT_CHECK_ARG(p.ksplit <= 1 && !p.tn, "gemm_bf16: split-K / TN need the 256 x 256 tile");

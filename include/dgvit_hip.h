@@ -260,6 +260,9 @@ int dgvit_gemm_bf16(int epilogue, const unsigned short* A, int lda, const unsign
                     const unsigned short* aux, int ldaux, void* stream);
 /* test/bench knob: force the bf16 GEMM workgroup tile (0 = automatic; 256256, 256128, 128128) */
 void dgvit_set_gemm_bf16_tile(int tile);
+/* A/B knob: which MFMA the ring GEMM issues: 1 (default) v_mfma_f32_16x16x32_bf16, 0 v_mfma_f32_32x32x16_bf16 (same cycles per
+ * FLOP; the kernel runs under the chip's power limit and the 16x16 shape measured 2-3 % faster; same results up to summation order) */
+void dgvit_set_gemm_bf16_mfma16(int on);
 /* diagnostic (tools/bf16_stamps.py): non-NULL = the epilogue-0 ring GEMM runs its stamped build and writes, per workgroup,
  * 2 wave groups x 8 tiles x 4 int64 {s_memtime at tile start / after its main loop / after its epilogue, s_memrealtime}
  * to this device buffer (256 workgroups at most); NULL (default) = shipped kernels, no stamp executes. */

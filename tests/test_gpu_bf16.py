@@ -24,6 +24,16 @@ def F():
     return dgvit_amd.functional
 
 
+@pytest.fixture(params=[0, 1], ids=["mfma32x32x16", "mfma16x16x32"])
+def mfma16(request):
+    """both MFMA shapes of the ring GEMM (A/B knob dgvit_set_gemm_bf16_mfma16), restored afterwards"""
+    import dgvit_amd
+    lib = dgvit_amd.load_library()
+    lib.dgvit_set_gemm_bf16_mfma16(request.param)
+    yield request.param
+    lib.dgvit_set_gemm_bf16_mfma16(1)
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g, dtype=torch.float64) * scale
@@ -57,7 +67,7 @@ GEMM_SHAPES = [(256, 256, 64), (512, 768, 768), (200, 136, 104), (50, 64, 256), 
 
 @pytest.mark.parametrize("tile", [0, 128128, 256128, 256256])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_gemm_bf16_f32_out_bias_residual(F, M, N, K, tile):
+def test_gemm_bf16_f32_out_bias_residual(F, mfma16, M, N, K, tile):
     """fp32 output = exact products of bf16 operands summed in fp32: error is accumulation only"""
     import dgvit_amd
     lib = dgvit_amd.load_library()
@@ -72,7 +82,7 @@ def test_gemm_bf16_f32_out_bias_residual(F, M, N, K, tile):
 
 @pytest.mark.parametrize("tile", [0, 256256, 256128])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (200, 136, 104), (591, 2304, 768), (37, 132, 264), (5000, 1540, 72)])
-def test_gemm_bf16_bf16_out_and_gelu(F, M, N, K, tile):
+def test_gemm_bf16_bf16_out_and_gelu(F, mfma16, M, N, K, tile):
     import dgvit_amd
     lib = dgvit_amd.load_library()
     lib.dgvit_set_gemm_bf16_tile(tile)
@@ -101,13 +111,23 @@ def _gemm_bf16_outputs(F, M, N, K):
     close(y4, a @ b.T, atol=2e-5 * K ** 0.5, msg="plain fp32")
 
 
-def test_gemm_bf16_identity_asymmetric(F):
+def test_gemm_bf16_identity_asymmetric(F, mfma16):
     """A = I with an asymmetric integer B catches any row/column or k-order mix-up exactly"""
-    n = 256
+    import dgvit_amd
+    lib = dgvit_amd.load_library()
+    n = 512
     a = torch.eye(n, dtype=torch.float64)
     b = (torch.arange(n, dtype=torch.float64)[:, None] * 3 + torch.arange(n, dtype=torch.float64)[None, :] % 7) % 251
-    y = F.op_gemm_bf16(4, dbf(a), dbf(b))
-    assert torch.equal(y.cpu().double(), b.T.contiguous())
+    for tile in (0, 256256, 256128):
+        lib.dgvit_set_gemm_bf16_tile(tile)
+        try:
+            y = F.op_gemm_bf16(4, dbf(a), dbf(b))
+        finally:
+            lib.dgvit_set_gemm_bf16_tile(0)
+        assert torch.equal(y.cpu().double(), b.T.contiguous()), tile
+    # TN form: dW = A^T B with A = I picks out B
+    dw = F.op_wgrad_bf16(dbf(a), dbf(b), want_bias=False)
+    assert torch.equal(dw.cpu().double(), b)
 
 
 @pytest.mark.parametrize("rows,D", [(8, 64), (1001, 256), (197 * 2, 768), (5, 1024), (33, 520)])
@@ -227,7 +247,7 @@ def test_encoder_bf16_dtype_switch():
 # ---------------------------------------------------------------------------------------------- backward
 @pytest.mark.parametrize("T,Mo,Ko", [(394, 136, 264), (4000, 768, 2304), (9001, 256, 256), (64, 8, 8), (20000, 3072, 768), (33, 520, 264),
                                      (1, 256, 256)])
-def test_wgrad_bf16(F, T, Mo, Ko):
+def test_wgrad_bf16(F, mfma16, T, Mo, Ko):
     """dW = dY^T X with the split-K GEMM in its TN layout, straight from the token-major operands (transposed LDS reads);
     db = column sums"""
     dy, x = rb(rnd(T, Mo, seed=1)), rb(rnd(T, Ko, seed=2))

@@ -35,8 +35,11 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--tiles", default="256256,256128,128128")
     ap.add_argument("--no-forward", action="store_true")
+    ap.add_argument("--mfma16", type=int, default=-1, help="force the ring GEMM's MFMA shape: 1 = 16x16x32, 0 = 32x32x16 (default: library default)")
     a = ap.parse_args()
     lib = dgvit_amd.load_library()
+    if a.mfma16 >= 0:
+        lib.dgvit_set_gemm_bf16_mfma16(a.mfma16)
     B, N, D, I, M = a.batch, 197, 768, 768, 3072
     T = B * N
     out = {"batch": B}
