@@ -122,9 +122,12 @@ def sac_step(dgvit_amd, synthetic, B, dev, steps=5):
             "note": "transformer actor + transformer critic, DRL.py:390-432 arithmetic"}
 
 
-def c5_bf16(dgvit_amd, lib, _lib, dev, batch=256, steps=10):
+def c5_bf16(dgvit_amd, lib, _lib, dev, batch=440, steps=10):
     """Secondary number: BASELINE config 5 (224x224 depth frames, 12-layer ViT-Base variant with goal token, bf16 storage /
-    fp32 accumulate), forward only, one GPU.  FLOPs per frame: SURVEY 8(d) dense figure (34.972 GFLOP)."""
+    fp32 accumulate), forward only, one GPU.  FLOPs per frame: SURVEY 8(d) dense figure (34.972 GFLOP).  The config leaves the batch
+    free ("B chosen to fill the GPU"): 440 frames = 86 680 token rows = 339 row panels of 256, so the 256 x 256 tile counts of the
+    layer GEMMs (x3, x9, x12 column panels) fall just under whole multiples of the 256 CUs; at B = 256 the N = 768 GEMMs run 591 tiles
+    = 2.31 rounds (DESIGN 3.5 holds both)."""
     import synthetic
     torch.manual_seed(5)
     m = dgvit_amd.GoT(image_size=224, patch_size=16, num_classes=2, dim=768, depth=12, heads=12, mlp_dim=3072, channels=1)
@@ -168,7 +171,7 @@ def c5_bf16(dgvit_amd, lib, _lib, dev, batch=256, steps=10):
     return {"workload": f"C5: GoT 224x224@16x16, L12 H12 D768 M3072 (N=197), forward, batch {batch}, bf16 storage / fp32 accumulate",
             "frames_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "dtype": "bf16",
             "tflops_dense": round(batch / dt * fwd / 1e12, 1), "frac_of_bf16_peak": round(batch / dt * fwd / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_ring_kernel", "achieved": round(gemm_tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
+            "batch": batch, "roofline": {"bound": "mfma", "kernel": "gemm_bf16_ring_kernel", "achieved": round(gemm_tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(gemm_tf / PEAK_BF16_MFMA_TFLOPS, 4),
                          "avg_launch_ms": round(ms[0] / max(1, cnt[0]), 5), "launches_per_step": int(cnt[0] // steps)},
             "gemm_ms_per_step": round(ms[0] / steps, 3), "attn_fwd_ms_per_step": round(ms[1] / steps, 3),
