@@ -261,6 +261,23 @@ def main():
     dt = tmax.item()
     final_loss = loss.item()
 
+    # A/B outside the timed region (N = 1 only): the same step with each layer's weight-gradient GEMMs on the library's helper
+    # stream.  Not the headline: concurrent kernels stretch each other's durations, so no per-kernel roofline can be quoted for it.
+    overlap_ab = None
+    if world == 1 and not args.wgrad_overlap:
+        lib.dgvit_set_wgrad_overlap(1)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dto = (time.perf_counter() - t0) / args.steps
+        lib.dgvit_set_wgrad_overlap(0)
+        overlap_ab = {"frames_per_s": round(B / dto, 1), "ms_per_step": round(dto * 1e3, 3),
+                      "note": "same step, weight-gradient GEMMs on a helper stream beside the data-gradient chain (DESIGN 3.3); not the headline"}
+
     if rank == 0:
         frames = B * world * args.steps
         fps = frames / dt
@@ -294,6 +311,8 @@ def main():
                            "gemm_ms_per_step": round(ms[0] / args.steps, 3), "attn_fwd_ms_per_step": round(ms[1] / args.steps, 3),
                            "attn_bwd_ms_per_step": round(ms[2] / args.steps, 3), "final_loss": round(final_loss, 5)},
         }
+        if overlap_ab:
+            out["wgrad_overlap_ab"] = overlap_ab
         if world == 1 and not args.no_sac_step:
             out["sac_step"] = sac_step(dgvit_amd, synthetic, B, dev)
         if world == 1 and not args.no_c5:

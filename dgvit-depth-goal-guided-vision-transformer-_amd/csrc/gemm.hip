@@ -10,8 +10,9 @@
 //   * a k-contiguous operand is staged as LDS[row][BK+4] and read back with one ds_read_b128 per
 //     32-row MFMA tile and 8-deep k-group (lane (i, h) takes k = 8g + 4h .. +3; the +4 pad makes the
 //     16-lane b128 groups hit 16 distinct 16-byte bank slots);
-//   * an m/n-contiguous operand is staged as LDS[k][R+4] and read with ds_read_b32 (32 consecutive
-//     floats per half-wave, conflict free);
+//   * an m/n-contiguous operand is staged as LDS[k][R+4]; a wave's 32-row MFMA tiles are interleaved over its rows (frag_mc) so
+//     that one ds_read_b64 per k-row feeds two tiles (256 B/clk; ds_read_b32 runs at 128 B/clk and made the TN / NN forms
+//     12 % / 6 % slower than NT on large problems);
 //   both read paths feed MFMA step s of k-group g with k = 8g + 4h + s, so the contraction order is the
 //   same permutation for A and B whatever their layouts.
 // Global->LDS staging is register-staged and double-buffered in LDS: tile t+1 is fetched to VGPRs
@@ -60,7 +61,7 @@ struct Fetch {
     __amdgpu_buffer_rsrc_t rsrc;
     unsigned off[NV];   // byte offset of slot i at the block's first k-tile
     int kc[NV];         // KC: k offset of the slot inside a tile; MC: k row of the slot inside a tile
-    bool ok[NV];        // MC: column in range
+    unsigned bad[NV];   // MC: all ones when the slot's columns lie outside the matrix (OR-ed into the offset: no branch), else 0
     unsigned kstep;     // bytes to advance per k-tile
   };
 
@@ -87,11 +88,11 @@ struct Fetch {
       if (KC) {
         pl.off[i] = ((unsigned)a * (unsigned)ld + (unsigned)c) * 4u;
         pl.kc[i] = c;
-        pl.ok[i] = true;  // rows past rmax fall outside num_records
+        pl.bad[i] = 0u;  // rows past rmax fall outside num_records
       } else {
         pl.off[i] = ((unsigned)a * (unsigned)ld + (unsigned)c) * 4u;
         pl.kc[i] = a;
-        pl.ok[i] = r0 + c < rmax;
+        pl.bad[i] = r0 + c < rmax ? 0u : 0xFFFFFFFFu;
       }
     }
   }
@@ -100,8 +101,8 @@ struct Fetch {
   __device__ static __forceinline__ void run4(float4 (&reg)[NV], const Plan& pl, int t, int klim) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const bool in = pl.ok[i] && (t * BK + pl.kc[i] < klim);
-      const unsigned o = in ? pl.off[i] + (unsigned)t * pl.kstep : DGVIT_OOB;
+      const unsigned at = (pl.off[i] + (unsigned)t * pl.kstep) | pl.bad[i];   // num_records <= 0x7FFFFFFF: all ones is out of range
+      const unsigned o = t * BK + pl.kc[i] < klim ? at : DGVIT_OOB;
       reg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(pl.rsrc, o, 0, 0));
     }
   }
@@ -158,6 +159,28 @@ __device__ __forceinline__ void frag(float (&out)[4], const float* lds, int row,
     const float* p = lds + (8 * g + 4 * h) * (R + 4) + row;
 #pragma unroll
     for (int s = 0; s < 4; ++s) out[s] = p[s * (R + 4)];
+  }
+}
+
+// m/n-contiguous operand, the wave's NTILE 32-row MFMA tiles INTERLEAVED: lane i of tile t owns row base + NTILE * i + t, so the
+// NTILE values a lane needs from one k-row are adjacent in LDS and come in with one ds_read_b64 / b128 (256 B/clk) instead of NTILE
+// ds_read_b32 (128 B/clk).  The permutation of the tile's rows is undone where the accumulators are written out.
+template <int R, int NTILE>
+__device__ __forceinline__ void frag_mc(float (&out)[NTILE][4], const float* lds, int base, int li, int g, int h) {
+  typedef float vec_t __attribute__((ext_vector_type(NTILE == 1 ? 1 : NTILE == 2 ? 2 : 4)));
+  static_assert(NTILE == 1 || NTILE == 2 || NTILE == 4, "frag_mc: tiles per wave");
+  const float* p = lds + (8 * g + 4 * h) * (R + 4) + base + NTILE * li;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if constexpr (NTILE == 1) {
+      out[0][s] = p[s * (R + 4)];
+    } else {
+      // volatile: keeps LLVM from pairing two of these into one ds_read2_b64, which runs at half the rate of two ds_read_b64
+      typedef __attribute__((address_space(3))) const volatile vec_t lds_vec_t;
+      const vec_t v = *(lds_vec_t*)(p + s * (R + 4));
+#pragma unroll
+      for (int t = 0; t < NTILE; ++t) out[t][s] = v[t];
+    }
   }
 }
 
@@ -237,10 +260,18 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
 
   // LDS -> fragments of one 8-deep k-group; MFMAs of one k-group
   auto load_frags = [&](float (&fa)[TM][4], float (&fb)[TN][4], const float* la, const float* lb, int g) {
+    if constexpr (AKC) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) frag<BM, BK, AKC>(fa[i], la, wm * WM + i * 32 + li, g, h);
+      for (int i = 0; i < TM; ++i) frag<BM, BK, true>(fa[i], la, wm * WM + i * 32 + li, g, h);
+    } else {
+      frag_mc<BM, TM>(fa, la, wm * WM, li, g, h);
+    }
+    if constexpr (BKC) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) frag<BN, BK, BKC>(fb[j], lb, wn * WN + j * 32 + li, g, h);
+      for (int j = 0; j < TN; ++j) frag<BN, BK, true>(fb[j], lb, wn * WN + j * 32 + li, g, h);
+    } else {
+      frag_mc<BN, TN>(fb, lb, wn * WN, li, g, h);
+    }
   };
   auto do_mfma = [&](const float (&fa)[TM][4], const float (&fb)[TN][4]) {
 #pragma unroll
@@ -291,7 +322,7 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
         if (g + 1 < BK / 8) load_frags(fa[(g + 1) & 1], fb[(g + 1) & 1], la, lb, g + 1);
         do_mfma(fa[g & 1], fb[g & 1]);
       }
-      sched_pattern<4 * TM * TN, FA::NV + FB::NV, (AKC ? TM : 4 * TM) + (BKC ? TN : 4 * TN), BK / 8>();
+      sched_pattern<4 * TM * TN, FA::NV + FB::NV, (AKC ? TM : (TM == 1 ? 2 : 4)) + (BKC ? TN : (TN == 1 ? 2 : 4)), BK / 8>();
       if (EPI == EPI_SPLITK && do_colsum) {
 #pragma unroll 8
         for (int kk = 0; kk < BK; ++kk) bsum += la[kk * (BM + 4) + tid];
@@ -351,13 +382,25 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
   for (int ch = 0; ch < NCHUNK; ++ch) {
     if (NCHUNK == 1 || wm == ch) {
       const int rbase = NCHUNK == 1 ? wm * WM : 0;
+      // (an m/n-contiguous operand's tiles are interleaved, see frag_mc: tile-row rt of tile i is row TM * rt + i, and likewise
+      //  for columns, where a lane's TN values are adjacent and leave as one vector write)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int r = 0; r < 16; ++r) {
+          const int rt = (r & 3) + 8 * (r >> 2) + 4 * h;
+          float* crow = smem + (rbase + (AKC ? i * 32 + rt : rt * TM + i)) * CS + wn * WN;
+          if constexpr (BKC || TN == 1) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            smem[(rbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * CS + wn * WN + j * 32 + li] = acc[i][j][r];
+            for (int j = 0; j < TN; ++j) crow[j * 32 + li] = acc[i][j][r];
+          } else {
+            typedef float cvec_t __attribute__((ext_vector_type(TN)));
+            cvec_t v;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
+            *reinterpret_cast<cvec_t*>(crow + li * TN) = v;
+          }
+        }
     }
     __syncthreads();
     if (n < p.N) {
