@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--no-sac-step", action="store_true", help="skip the secondary full SAC-style step measurement")
+    ap.add_argument("--no-overlap-ab", action="store_true", help="skip the helper-stream A/B after the timed region (use when profiling: it launches the same kernels)")
     ap.add_argument("--no-c5", action="store_true", help="skip the secondary config-5 (224x224 ViT-Base, bf16) forward measurement")
     ap.add_argument("--wgrad-overlap", action="store_true", help="A/B: weight-gradient GEMMs on the helper stream (+5%% frames/s, blurs per-kernel timing)")
     ap.add_argument("--dense-last-block", action="store_true", help="A/B: compute the last block for every token")
@@ -264,7 +265,7 @@ def main():
     # A/B outside the timed region (N = 1 only): the same step with each layer's weight-gradient GEMMs on the library's helper
     # stream.  Not the headline: concurrent kernels stretch each other's durations, so no per-kernel roofline can be quoted for it.
     overlap_ab = None
-    if world == 1 and not args.wgrad_overlap:
+    if world == 1 and not args.wgrad_overlap and not args.no_overlap_ab:
         lib.dgvit_set_wgrad_overlap(1)
         for _ in range(2):
             step()
