@@ -36,6 +36,21 @@ def _table(tensors: Sequence[torch.Tensor]):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+def _empty_batch(shape, tensors):
+    """The reference's behaviour for an empty batch (its torch ops accept 0-row tensors): an empty result, no kernel launch, and a
+    backward that hands every live parameter a zero gradient of its own shape."""
+    for t in tensors:
+        if isinstance(t, torch.Tensor):
+            _dev(t, "input")          # still a device-only path: CPU tensors are refused as everywhere else
+    like = next(t for t in tensors if isinstance(t, torch.Tensor))
+    out = like.new_zeros(shape)
+    if torch.is_grad_enabled():
+        live = [t for t in tensors if isinstance(t, torch.Tensor) and t.requires_grad]
+        if live:
+            out = out + sum(t.reshape(-1)[:1].sum() for t in live) * 0.0
+    return out
+
+
 def make_config(image, patch, dim, depth, heads, dim_head, mlp_dim) -> dgvit_config:
     return dgvit_config(int(image[0]), int(image[1]), int(patch[0]), int(patch[1]), int(dim), int(depth), int(heads),
                         int(dim_head), int(mlp_dim), 0)
@@ -105,6 +120,8 @@ class _GoTEncoder(torch.autograd.Function):
 
 def got_encoder(img, goal, cfg_tuple, params, dropout_keep=1.0, dropout_seed=0):
     """feat (B, D) = GoT.forward(img (B,H,W), goal (B,D)); params in the table order of dgvit_hip.h."""
+    if img.shape[0] == 0:
+        return _empty_batch((0, int(cfg_tuple[4])), [img, goal, *params])
     need_grad = torch.is_grad_enabled() and (goal.requires_grad or any(p.requires_grad for p in params))
     return _GoTEncoder.apply(img, goal, tuple(cfg_tuple), dropout_keep, dropout_seed, need_grad, *params)
 
@@ -155,6 +172,8 @@ class _CnnStack(torch.autograd.Function):
 
 def cnn_features(img, conv_params):
     """(B, H, W) frames -> (B, 256) pooled features; conv_params = [w1, b1, w2, b2, w3, b3] (reference layouts)."""
+    if img.shape[0] == 0:
+        return _empty_batch((0, 256), [img, *conv_params])
     need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in conv_params)
     return _CnnStack.apply(img, need_grad, *conv_params)
 
@@ -199,6 +218,8 @@ class _Linear(torch.autograd.Function):
 
 def linear(x, weight, bias=None, relu=False):
     """y = x W^T + b, optionally ReLU'd, on the MFMA GEMM."""
+    if isinstance(x, torch.Tensor) and x.dim() == 2 and x.shape[0] == 0 and isinstance(weight, torch.Tensor):
+        return _empty_batch((0, weight.shape[0]), [x, weight, bias])
     return _Linear.apply(x, weight, bias, 1 if relu else 0)
 
 
@@ -480,5 +501,7 @@ class _GoTEncoderBf16(torch.autograd.Function):
 
 def got_encoder_bf16(img, goal, cfg_tuple, params, weights: Bf16Weights, dropout_keep=1.0, dropout_seed=0):
     """GoT.forward in the bf16 configuration (bf16 storage of GEMM operands, fp32 master parameters and gradients)."""
+    if img.shape[0] == 0:
+        return _empty_batch((0, int(cfg_tuple[4])), [img, goal, *params])
     need_grad = torch.is_grad_enabled() and (goal.requires_grad or any(p.requires_grad for p in params))
     return _GoTEncoderBf16.apply(img, goal, tuple(cfg_tuple), dropout_keep, dropout_seed, need_grad, weights, *params)

@@ -571,3 +571,27 @@ def test_got_meanpool_golden(amd):
         if f"gfull/{k}" in fx:
             ref = fx[f"gfull/{k}"]
             np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=GRAD_RTOL, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=k)
+
+
+def test_empty_batch_like_reference(amd):
+    """Zero frames.  The reference's GoTPolicy returns (0, 2) tensors and, after backward, zero gradients for every parameter on
+    the path (None for cls_token / mlp_head); its GoTQNetwork raises RuntimeError (view(0, -1), got_sac_network.py:113).  Both
+    checked by running the reference here; the HIP path must not launch on an empty problem and must behave the same."""
+    m = amd.GoTPolicy(2, 2, 2, 2, 64).cuda().train()
+    mean, log_std = m([torch.zeros(0, 128, 160, device="cuda"), torch.zeros(0, 2, device="cuda")])
+    assert mean.shape == (0, 2) and log_std.shape == (0, 2)
+    (mean.sum() + log_std.sum()).backward()
+    none = sorted(k for k, p in m.named_parameters() if p.grad is None)
+    assert none == sorted(["trans.cls_token", "trans.mlp_head.0.weight", "trans.mlp_head.0.bias", "trans.mlp_head.1.weight",
+                           "trans.mlp_head.1.bias"])
+    assert all(float(p.grad.abs().sum()) == 0.0 and p.grad.shape == p.shape for p in m.parameters() if p.grad is not None)
+    a, lp, mu = m.sample([torch.zeros(0, 128, 160, device="cuda"), torch.zeros(0, 2, device="cuda")])
+    assert a.shape == (0, 2) and lp.shape == (0, 1) and mu.shape == (0, 2)
+    got = amd.GoT(image_size=(84, 84), patch_size=(12, 12), num_classes=2, dim=64, depth=1, heads=2, mlp_dim=64, channels=1).cuda()
+    assert got(torch.zeros(0, 84, 84, device="cuda"), torch.zeros(0, 64, device="cuda")).shape == (0, 64)
+    assert got.set_compute_dtype(torch.bfloat16)(torch.zeros(0, 84, 84, device="cuda"), torch.zeros(0, 64, device="cuda")).shape == (0, 64)
+    q = amd.GoTQNetwork(2, 2, 2, 2, 64).cuda()
+    with pytest.raises(RuntimeError):
+        q([torch.zeros(0, 128, 160, device="cuda"), torch.zeros(0, 2, device="cuda"), torch.zeros(0, 2, device="cuda")])
+    with pytest.raises(amd.DgvitError):          # still no CPU fallback, empty or not
+        m([torch.zeros(0, 128, 160), torch.zeros(0, 2)])
