@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--no-sac-step", action="store_true", help="skip the secondary full SAC-style step measurement")
+    ap.add_argument("--profile-stride", type=int, default=10, help="time every n-th launch of each kernel kind with HIP events (1 = every launch)")
     ap.add_argument("--no-overlap-ab", action="store_true", help="skip the helper-stream A/B after the timed region (use when profiling: it launches the same kernels)")
     ap.add_argument("--no-c5", action="store_true", help="skip the secondary config-5 (224x224 ViT-Base, bf16) forward measurement")
     ap.add_argument("--wgrad-overlap", action="store_true", help="A/B: weight-gradient GEMMs on the helper stream (+5%% frames/s, blurs per-kernel timing)")
@@ -139,6 +140,7 @@ def c5_bf16(dgvit_amd, lib, _lib, dev, batch=440, steps=10):
         for _ in range(3):
             m(img, goal)
         torch.cuda.synchronize()
+        lib.dgvit_profile_sampling(7)          # events around every 7th launch of a kind (7 and 50 GEMM launches per pass: coprime)
         lib.dgvit_profile_start(4096)
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -148,6 +150,12 @@ def c5_bf16(dgvit_amd, lib, _lib, dev, batch=440, steps=10):
     kinds = _lib.PROFILE_KINDS
     ms, work, cnt = (ctypes.c_double * kinds)(), (ctypes.c_double * kinds)(), (ctypes.c_longlong * kinds)()
     lib.dgvit_profile_stop(ms, work, cnt)
+    work_all, cnt_all = (ctypes.c_double * kinds)(), (ctypes.c_longlong * kinds)()
+    lib.dgvit_profile_totals(work_all, cnt_all)
+    lib.dgvit_profile_sampling(1)
+
+    def per_step(k):   # sampled average launch duration x launches of that kind per pass
+        return ms[k] / max(1, cnt[k]) * cnt_all[k] / steps
     fwd = synthetic.fwd_flops_per_frame((224, 224), (16, 16), 768, 12, 12, mlp_dim=3072)
     gemm_tf = (work[0] / 1e12) / (ms[0] / 1e3) if ms[0] > 0 else 0.0
     # forward + backward in train mode (dense last block, activations kept, fp32 master gradients), no optimiser step
@@ -174,9 +182,10 @@ def c5_bf16(dgvit_amd, lib, _lib, dev, batch=440, steps=10):
             "tflops_dense": round(batch / dt * fwd / 1e12, 1), "frac_of_bf16_peak": round(batch / dt * fwd / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
             "batch": batch, "roofline": {"bound": "mfma", "kernel": "gemm_bf16_ring_kernel", "achieved": round(gemm_tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(gemm_tf / PEAK_BF16_MFMA_TFLOPS, 4),
-                         "avg_launch_ms": round(ms[0] / max(1, cnt[0]), 5), "launches_per_step": int(cnt[0] // steps)},
-            "gemm_ms_per_step": round(ms[0] / steps, 3), "attn_fwd_ms_per_step": round(ms[1] / steps, 3),
-            "norm_ms_per_step": round(ms[3] / steps, 3), "fwd_bwd": train}
+                         "avg_launch_ms": round(ms[0] / max(1, cnt[0]), 5), "launches_per_step": int(cnt_all[0] // steps),
+                         "launches_timed": int(cnt[0])},
+            "gemm_ms_per_step": round(per_step(0), 3), "attn_fwd_ms_per_step": round(per_step(1), 3),
+            "norm_ms_per_step": round(per_step(3), 3), "fwd_bwd": train}
 
 
 def main():
@@ -243,7 +252,11 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    lib.dgvit_profile_start(4096)
+    # live kernel timing inside the timed region: HIP events around every PROFILE_STRIDE-th launch of each kind.  (An event pair
+    # isolates its launch from its neighbours; around every launch that slows this step by ~7 %.  10 and 91 GEMM launches per step
+    # are coprime, so every launch site is sampled over the steps.)
+    lib.dgvit_profile_sampling(args.profile_stride)
+    lib.dgvit_profile_start(8192)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -255,6 +268,10 @@ def main():
     work = (ctypes.c_double * kinds)()
     cnt = (ctypes.c_longlong * kinds)()
     lib.dgvit_profile_stop(ms, work, cnt)
+    work_all = (ctypes.c_double * kinds)()
+    cnt_all = (ctypes.c_longlong * kinds)()
+    lib.dgvit_profile_totals(work_all, cnt_all)
+    lib.dgvit_profile_sampling(1)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -284,6 +301,10 @@ def main():
         fps = frames / dt
         fwd = synthetic.fwd_flops_per_frame(IMAGE, PATCH, DIM, DEPTH, HEADS)
         gemm_tflops = (work[0] / 1e12) / (ms[0] / 1e3) if ms[0] > 0 else 0.0
+
+        def per_step(k):   # sampled average launch duration x launches of that kind per step
+            return ms[k] / max(1, cnt[k]) * cnt_all[k] / args.steps
+
         traffic = None
         try:   # HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (tools/pmc_traffic.py)
             with open(os.path.join(ROOT, "profiles", "r01_c_hbm_traffic.json")) as f:
@@ -305,12 +326,16 @@ def main():
                          "frac": round(gemm_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes (profiles/r01_c_hbm_traffic.json)",
                          "kernel": "gemm_f32_kernel (all instantiations: NT fwd, NN dgrad, TN wgrad)",
-                         "launches_per_step": int(cnt[0] // max(1, args.steps)),
+                         "launches_per_step": int(cnt_all[0] // max(1, args.steps)),
                          "avg_launch_ms": round(ms[0] / max(1, cnt[0]), 5),
-                         "avg_launch_gflop": round(work[0] / max(1, cnt[0]) / 1e9, 4)},
+                         "avg_launch_gflop": round(work[0] / max(1, cnt[0]) / 1e9, 4),
+                         "launches_timed": int(cnt[0]), "launches_in_region": int(cnt_all[0]),
+                         "timing": f"HIP events around every {args.profile_stride}-th launch of the kernel inside the timed region"},
             "end_to_end": {"tflops": round(fps * 3 * fwd / 1e12, 2), "frac_of_peak": round(fps * 3 * fwd / 1e12 / world / PEAK_F32_MFMA_TFLOPS, 4),
-                           "gemm_ms_per_step": round(ms[0] / args.steps, 3), "attn_fwd_ms_per_step": round(ms[1] / args.steps, 3),
-                           "attn_bwd_ms_per_step": round(ms[2] / args.steps, 3), "final_loss": round(final_loss, 5)},
+                           "gemm_ms_per_step": round(per_step(0), 3), "attn_fwd_ms_per_step": round(per_step(1), 3),
+                           "attn_bwd_ms_per_step": round(per_step(2), 3), "final_loss": round(final_loss, 5),
+                           "per_step_note": "isolated launch durations (sampled) x launches per step; back-to-back launches overlap "
+                                            "at their edges, so these can add up to more than ms_per_step"},
         }
         if overlap_ab:
             out["wgrad_overlap_ab"] = overlap_ab

@@ -22,7 +22,7 @@ class dgvit_config(Structure):
 
 NUM_GLOBAL_PARAMS = 4
 PARAMS_PER_LAYER = 11
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _P, _I, _LL, _F, _ULL = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 _CFG = POINTER(dgvit_config)
@@ -87,6 +87,8 @@ SIGNATURES = {
     "dgvit_attention_backward_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dgvit_profile_start": (_I, [_I]),
     "dgvit_profile_stop": (_I, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_longlong)]),
+    "dgvit_profile_sampling": (_I, [_I]),
+    "dgvit_profile_totals": (_I, [POINTER(ctypes.c_double), POINTER(c_longlong)]),
 }
 PROFILE_KINDS = 4
 

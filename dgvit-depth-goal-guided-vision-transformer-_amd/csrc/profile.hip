@@ -1,4 +1,4 @@
-// Optional in-library kernel timing: HIP events recorded on the launch stream around each kernel launch.
+// Optional in-library kernel timing: HIP events recorded on the launch stream around kernel launches (all, or every s-th).
 // bench.py switches it on for the timed region to get the dominant kernel's live average launch duration
 // (the roofline figure) without an external profiler; it is off by default and costs nothing then.
 #include <mutex>
@@ -16,13 +16,20 @@ std::mutex g_mu;
 std::vector<Rec> g_recs;
 size_t g_used = 0;
 bool g_on = false;
+int g_stride = 1;                            // time every g_stride-th launch of each kind
+long long g_seen[DGVIT_PROFILE_KINDS] = {};  // all launches between start and stop, per kind
+double g_work_all[DGVIT_PROFILE_KINDS] = {};
 }  // namespace
 
 // returns a slot index (>= 0) when this launch is being timed, -1 otherwise
 int profile_begin(int kind, double work, hipStream_t st) {
   if (!g_on) return -1;
   std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_on || g_used >= g_recs.size()) return -1;
+  if (!g_on) return -1;
+  const int kk = kind >= 0 && kind < DGVIT_PROFILE_KINDS ? kind : DGVIT_PROFILE_KINDS - 1;
+  const long long seen = g_seen[kk]++;
+  g_work_all[kk] += work;
+  if (seen % g_stride != 0 || g_used >= g_recs.size()) return -1;
   Rec& r = g_recs[g_used];
   r.kind = kind;
   r.work = work;
@@ -47,7 +54,27 @@ extern "C" int dgvit_profile_start(int max_records) {
     g_recs.push_back(r);
   }
   g_used = 0;
+  for (int k = 0; k < DGVIT_PROFILE_KINDS; ++k) {
+    g_seen[k] = 0;
+    g_work_all[k] = 0;
+  }
   g_on = true;
+  return DGVIT_OK;
+}
+
+extern "C" int dgvit_profile_sampling(int stride) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  DGVIT_CHECK_ARG(stride >= 1 && stride <= (1 << 20), "profile_sampling: stride must be >= 1");
+  g_stride = stride;
+  return DGVIT_OK;
+}
+
+extern "C" int dgvit_profile_totals(double* work_all, long long* launches_all) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int k = 0; k < DGVIT_PROFILE_KINDS; ++k) {
+    if (work_all) work_all[k] = g_work_all[k];
+    if (launches_all) launches_all[k] = g_seen[k];
+  }
   return DGVIT_OK;
 }
 

@@ -36,7 +36,7 @@ def test_library_exports_every_header_symbol(amd):
         assert hasattr(lib, name), f"libdgvit_hip.so does not export {name}"
         assert name in _lib.SIGNATURES, f"ctypes binding has no signature for {name}"
     assert sorted(_lib.SIGNATURES) == declared, "binding and header disagree"
-    assert lib.dgvit_abi_version() == 3
+    assert lib.dgvit_abi_version() == 4
 
 
 def test_size_queries_and_validation_without_gpu(amd):

@@ -207,3 +207,28 @@ def test_linear_autograd(F, M, N, K, relu):
     close(xg.grad, xr.grad, atol=2e-4)
     close(wg.grad, wr.grad, atol=2e-4 * math.sqrt(M))
     close(bg.grad, br.grad, atol=2e-4 * math.sqrt(M))
+
+
+def test_live_profile_sampling(F):
+    """dgvit_profile_*: every launch timed (stride 1) or every 3rd; totals count all launches either way."""
+    import ctypes
+    import dgvit_amd
+    from dgvit_amd import _lib
+    lib = dgvit_amd.load_library()
+    A, B = torch.randn(256, 128, device="cuda"), torch.randn(192, 128, device="cuda")
+    kinds = _lib.PROFILE_KINDS
+    for stride, timed in ((1, 10), (3, 4)):
+        assert lib.dgvit_profile_sampling(stride) == 0
+        assert lib.dgvit_profile_start(64) == 0
+        for _ in range(10):
+            F.op_gemm(0, 0, A, B, 256, 192, 128)
+        ms, work, cnt = (ctypes.c_double * kinds)(), (ctypes.c_double * kinds)(), (ctypes.c_longlong * kinds)()
+        assert lib.dgvit_profile_stop(ms, work, cnt) == 0
+        wall, call = (ctypes.c_double * kinds)(), (ctypes.c_longlong * kinds)()
+        assert lib.dgvit_profile_totals(wall, call) == 0
+        flops = 2.0 * 256 * 192 * 128
+        assert cnt[0] == timed and call[0] == 10
+        assert work[0] == timed * flops and wall[0] == 10 * flops
+        assert 0.0 < ms[0] < 50.0
+    lib.dgvit_profile_sampling(1)
+    assert lib.dgvit_profile_sampling(0) < 0
