@@ -198,6 +198,7 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch N>1 with torch.distributed.run", file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL; must be set before the first HIP call
     if not torch.cuda.is_available():
         print("bench.py needs a ROCm GPU", file=sys.stderr)
         sys.exit(2)
