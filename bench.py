@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=64)
     ap.add_argument("--no-sac-step", action="store_true", help="skip the secondary full SAC-style step measurement")
     ap.add_argument("--profile-stride", type=int, default=10, help="time every n-th launch of each kernel kind with HIP events (1 = every launch)")
-    ap.add_argument("--no-overlap-ab", action="store_true", help="skip the helper-stream A/B after the timed region (use when profiling: it launches the same kernels)")
+    ap.add_argument("--no-overlap-ab", action="store_true", help="skip the forward-only pass and the helper-stream A/B after the timed region (use when profiling: they launch the same kernels)")
     ap.add_argument("--no-c5", action="store_true", help="skip the secondary config-5 (224x224 ViT-Base, bf16) forward measurement")
     ap.add_argument("--wgrad-overlap", action="store_true", help="A/B: weight-gradient GEMMs on the helper stream (+5%% frames/s, blurs per-kernel timing)")
     ap.add_argument("--dense-last-block", action="store_true", help="A/B: compute the last block for every token")
@@ -280,6 +280,27 @@ def main():
     dt = tmax.item()
     final_loss = loss.item()
 
+    # north-star figure "MFMA roofline fraction of the DGViT forward at batch 512" (N = 1 only, outside the timed region):
+    # the same batch through the same model, inference mode, no timing events
+    forward_only = None
+    if world == 1 and not args.no_overlap_ab:
+        import synthetic as _syn
+        model.eval()
+        with torch.no_grad():
+            for _ in range(3):
+                model([img, pstate])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                model([img, pstate])
+            torch.cuda.synchronize()
+            dtf = (time.perf_counter() - t0) / args.steps
+        model.train()
+        ffl = _syn.fwd_flops_per_frame(IMAGE, PATCH, DIM, DEPTH, HEADS)
+        forward_only = {"frames_per_s": round(B / dtf, 1), "ms_per_pass": round(dtf * 1e3, 3), "tflops_dense": round(B / dtf * ffl / 1e12, 2),
+                        "frac_of_f32_mfma_peak": round(B / dtf * ffl / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                        "note": "GoTPolicy forward (eval, no_grad), B=512 84x84; dense FLOPs of SURVEY 8(d); target of the north star: >= 0.5"}
+
     # A/B outside the timed region (N = 1 only): the same step with each layer's weight-gradient GEMMs on the library's helper
     # stream.  Not the headline: concurrent kernels stretch each other's durations, so no per-kernel roofline can be quoted for it.
     overlap_ab = None
@@ -338,6 +359,8 @@ def main():
                            "per_step_note": "isolated launch durations (sampled) x launches per step; back-to-back launches overlap "
                                             "at their edges, so these can add up to more than ms_per_step"},
         }
+        if forward_only:
+            out["forward_only"] = forward_only
         if overlap_ab:
             out["wgrad_overlap_ab"] = overlap_ab
         if world == 1 and not args.no_sac_step:
