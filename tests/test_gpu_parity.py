@@ -595,3 +595,43 @@ def test_empty_batch_like_reference(amd):
         q([torch.zeros(0, 128, 160, device="cuda"), torch.zeros(0, 2, device="cuda"), torch.zeros(0, 2, device="cuda")])
     with pytest.raises(amd.DgvitError):          # still no CPU fallback, empty or not
         m([torch.zeros(0, 128, 160), torch.zeros(0, 2)])
+
+
+def test_training_trajectory_matches_oracle(amd):
+    """Drop-in training: four Adam steps of the actor (HIP forward + backward through the C ABI + the flat-buffer HIP Adam) against
+    the oracle trained with torch.optim.Adam on the CPU from the same weights, inputs and targets (eval mode: no dropout draw).
+    Losses agree step by step; parameters agree after the last step except where Adam's sign-like first updates amplify a
+    rounding-level gradient difference (a handful of elements whose gradient is ~0)."""
+    from dgvit_amd.optim import FlatAdam
+    cfg = O.GoTConfig(image=(84, 84), patch=(12, 12), dim=64, depth=2, heads=2)
+    params = O.make_params(O.policy_param_spec(cfg), 77)
+    m = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, image_size=cfg.image, patch_size=cfg.patch), params).eval().to("cuda")
+    opt = FlatAdam([m], lr=1e-3)
+    ref = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ropt = torch.optim.Adam(list(ref.values()), lr=1e-3)
+    img, pstate, _, _ = O.make_inputs(cfg, 16, 77)
+    g = torch.Generator().manual_seed(77)
+    tm, tl = torch.randn(16, 2, generator=g), torch.randn(16, 2, generator=g)
+    losses = []
+    for _ in range(4):
+        ropt.zero_grad()
+        rm, rl = O.policy_forward(ref, img, pstate, cfg)
+        rloss = ((rm - tm) ** 2).mean() + ((rl - tl) ** 2).mean()
+        rloss.backward()
+        ropt.step()
+        for p in m.parameters():
+            p.grad = None
+        mean, log_std = m([img.cuda(), pstate.cuda()])
+        loss = ((mean - tm.cuda()) ** 2).mean() + ((log_std - tl.cuda()) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append((loss.item(), rloss.item()))
+    for got, want in losses:
+        assert abs(got - want) <= 1e-4 * max(1.0, abs(want)), losses
+    assert losses[-1][0] < losses[0][0]
+    total = bad = 0
+    for k, p in m.state_dict().items():
+        d = (p.detach().cpu() - ref[k].detach()).abs()
+        total += d.numel()
+        bad += int((d > 1e-4).sum())
+    assert bad <= max(8, total // 2000), (bad, total)
