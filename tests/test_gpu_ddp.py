@@ -1,0 +1,74 @@
+"""GPU: the batch-sharded training path with the HIP kernels in it.  Two processes share the one card of the test box (gloo carries the
+gradients; RCCL needs one GPU per rank and is what bench.py uses on a node): each rank runs the HIP forward/backward on its half
+of the frames, GradSync all-reduces, and the averaged gradients must equal those of one process on the whole batch."""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+B = 8
+
+
+def _cfg():
+    return O.GoTConfig(image=(84, 84), patch=(12, 12), dim=64, depth=2, heads=2)
+
+
+def _model_and_data():
+    import dgvit_amd
+    cfg = _cfg()
+    params = O.make_params(O.policy_param_spec(cfg), 55)
+    m = dgvit_amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, image_size=cfg.image, patch_size=cfg.patch)
+    m.load_state_dict(params, strict=True)
+    m = m.to("cuda").eval()
+    img, pstate, _, _ = O.make_inputs(cfg, B, 55)
+    g = torch.Generator().manual_seed(55)
+    tgt = torch.randn(B, 2, generator=g)
+    return m, img.cuda(), pstate.cuda(), tgt.cuda()
+
+
+def _loss(m, img, pstate, tgt):
+    mean, log_std = m([img, pstate])
+    return ((mean - tgt) ** 2).mean() + (log_std ** 2).mean()
+
+
+def _worker(rank, world, tmp):
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dist.init_process_group("gloo", init_method=f"file://{tmp}/rdzv", rank=rank, world_size=world)
+    try:
+        from dgvit_amd.parallel import GradSync
+        m, img, pstate, tgt = _model_and_data()
+        per = B // world
+        sl = slice(rank * per, (rank + 1) * per)
+        sync = GradSync([m])
+        sync.zero_grad()
+        _loss(m, img[sl], pstate[sl], tgt[sl]).backward()
+        sync.sync()
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save({k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}, os.path.join(tmp, "grads.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_the_hip_path_match_one_process():
+    m, img, pstate, tgt = _model_and_data()
+    _loss(m, img, pstate, tgt).backward()
+    torch.cuda.synchronize()
+    want = {k: p.grad.detach().cpu() for k, p in m.named_parameters() if p.grad is not None}
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_worker, args=(2, tmp), nprocs=2, join=True)
+        got = torch.load(os.path.join(tmp, "grads.pt"), weights_only=True)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        tol = 2e-5 * float(want[k].abs().max()) + 1e-9
+        assert float((got[k] - want[k]).abs().max()) <= tol, k
