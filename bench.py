@@ -329,7 +329,7 @@ def main():
 
         traffic = None
         try:   # HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (tools/pmc_traffic.py)
-            with open(os.path.join(ROOT, "profiles", "r01_c_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01_m_hbm_traffic.json")) as f:
                 traffic = json.load(f)["kernels"]["gemm_f32_kernel"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -346,7 +346,7 @@ def main():
                        "wgrad_overlap": bool(args.wgrad_overlap)},
             "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes (profiles/r01_c_hbm_traffic.json)",
+                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes (profiles/r01_m_hbm_traffic.json)",
                          "kernel": "gemm_f32_kernel (all instantiations: NT fwd, NN dgrad, TN wgrad)",
                          "launches_per_step": int(cnt_all[0] // max(1, args.steps)),
                          "avg_launch_ms": round(ms[0] / max(1, cnt[0]), 5),
