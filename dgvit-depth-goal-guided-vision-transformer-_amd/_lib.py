@@ -22,7 +22,7 @@ class dgvit_config(Structure):
 
 NUM_GLOBAL_PARAMS = 4
 PARAMS_PER_LAYER = 11
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _P, _I, _LL, _F, _ULL = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 _CFG = POINTER(dgvit_config)
@@ -31,6 +31,7 @@ _TABLE = POINTER(c_void_p)
 # name -> (restype, argtypes); every symbol include/dgvit_hip.h declares
 SIGNATURES = {
     "dgvit_abi_version": (_I, []),
+    "dgvit_config_size": (_I, []),
     "dgvit_last_error": (c_char_p, []),
     "dgvit_device_count": (_I, []),
     "dgvit_got_workspace_floats": (_LL, [_CFG, _I, _I]),
@@ -70,7 +71,7 @@ SIGNATURES = {
     "dgvit_adam_step": (_I, [_P, _P, _P, _P, _LL, _F, _F, _F, _F, _F, _LL, _P, _P]),
     "dgvit_soft_update": (_I, [_P, _P, _LL, _F, _P]),
     "dgvit_got_bf16_weight_elems": (_LL, [_CFG]),
-    "dgvit_got_pack_weights_bf16": (_I, [_CFG, _TABLE, _P, _LL, _P]),
+    "dgvit_got_pack_weights_bf16": (_I, [_CFG, _TABLE, _P, _LL, _I, _P]),
     "dgvit_got_bf16_workspace_bytes": (_LL, [_CFG, _I, _I]),
     "dgvit_got_forward_bf16": (_I, [_CFG, _TABLE, _P, _P, _P, _P, _P, _LL, _I, _I, _F, _ULL, _P, _P]),
     "dgvit_got_bf16_backward_scratch_bytes": (_LL, [_CFG, _I]),
@@ -112,6 +113,8 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.dgvit_abi_version() != ABI_VERSION:
         raise DgvitError(f"ABI mismatch: library {lib.dgvit_abi_version()} != binding {ABI_VERSION}")
+    if lib.dgvit_config_size() != ctypes.sizeof(dgvit_config):
+        raise DgvitError(f"dgvit_config is {ctypes.sizeof(dgvit_config)} bytes in the binding, {lib.dgvit_config_size()} in the library")
     _lib = lib
     return lib
 

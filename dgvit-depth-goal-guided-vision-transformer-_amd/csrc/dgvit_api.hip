@@ -98,8 +98,14 @@ long long wgrad_slab(int M, int N) { return al4((long long)M * N + M); }
 long long wgrad_scratch(int M, int N, int K) { return (long long)wgrad_splits(M, N, K) * wgrad_slab(M, N); }
 
 // dW (M x N) = A^T B with A (K x M, lda), B (K x N, ldb); optional db (M) = column sums of A (fused in the kernel);
+// dW == nullptr: the weight is frozen (its requires_grad is off): only the bias gradient, if wanted, is computed.
 int wgrad(const float* A, int lda, const float* B, int ldb, float* dW, float* db, int M, int N, int K, float* scratch,
           long long scratch_floats, hipStream_t st) {
+  if (!dW) {
+    if (!db) return DGVIT_OK;
+    if (scratch_floats < (long long)colsum_blocks(K) * M) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "wgrad: scratch too small for the bias gradient");
+    return colsum(A, lda, db, scratch, K, M, 0, st);
+  }
   const int ns = wgrad_splits(M, N, K);
   const long long slab = wgrad_slab(M, N);
   if (scratch_floats < ns * slab) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "wgrad: scratch %lld < %lld floats", scratch_floats, ns * slab);
@@ -189,6 +195,7 @@ Ws make_ws(const Dims& d, int save) {
 
 // ---------------------------------------------------------------------------------------------- misc exports
 extern "C" int dgvit_abi_version(void) { return DGVIT_ABI_VERSION; }
+extern "C" int dgvit_config_size(void) { return (int)sizeof(dgvit_config); }
 extern "C" const char* dgvit_last_error(void) { return g_err; }
 extern "C" int dgvit_device_count(void) {
   int n = 0;
@@ -339,7 +346,7 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
   if (ws_floats < w.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "backward workspace %lld < %lld floats", ws_floats, w.total);
   if (scratch_floats < s.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "backward scratch %lld < %lld floats", scratch_floats, s.total);
   const int np = P_L0 + DGVIT_PARAMS_PER_LAYER * d.L;
-  for (int i = 0; i < np; ++i) DGVIT_CHECK_ARG(params[i] && grads[i], "parameter/gradient %d is null", i);
+  for (int i = 0; i < np; ++i) DGVIT_CHECK_ARG(params[i], "parameter %d is null", i);   // grads[i] == NULL: frozen parameter, its gradient is skipped
   const int T = (int)d.T;
   float* dx = scratch + s.dxa;    // gradient of the residual stream entering the current op
   float* dx2 = scratch + s.dxb;
@@ -413,7 +420,7 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
     } else {
       // dWq from the token-0 rows, dWk/dWv from all rows; dln1 = dkv Wkv (+ dq Wq on the token-0 rows)
       TRY(wgrad(dqkv, rs * 3 * d.I, lb + w.ln1, rs * d.D, lg[L_QKV], nullptr, d.I, d.D, tok, slabs, s.slabs_floats, sw));
-      TRY(wgrad(dqkv + d.I, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV] + (long long)d.I * d.D, nullptr, 2 * d.I, d.D, T, slabs,
+      TRY(wgrad(dqkv + d.I, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV] ? lg[L_QKV] + (long long)d.I * d.D : nullptr, nullptr, 2 * d.I, d.D, T, slabs,
                 s.slabs_floats, sw));
       GemmParams kv = gp(dqkv + d.I, 3 * d.I, lp[L_QKV] + (long long)d.I * d.D, d.D, dln, d.D, T, d.D, 2 * d.I);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, kv, 1, st));
@@ -431,7 +438,8 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
   if (dgoal)
     HIP_TRY(hipMemcpy2DAsync(dgoal, sizeof(float) * d.D, dx, sizeof(float) * d.N * d.D, sizeof(float) * d.D, d.B,
                              hipMemcpyDeviceToDevice, st));
-  TRY(colsum(dx, (long long)d.N * d.D, grads[P_POS], part, d.B, d.N * d.D, 0, st));  // dpos = sum over frames
+  if (grads[P_POS]) TRY(colsum(dx, (long long)d.N * d.D, grads[P_POS], part, d.B, d.N * d.D, 0, st));  // dpos = sum over frames
+  if (!grads[P_PW] && !grads[P_PB]) return DGVIT_OK;
   // patch rows of dx0 (token rows 1..P of every frame) packed densely, then dW_pe = dx_patch^T patches, db_pe = column sums
   HIP_TRY(hipMemcpy2DAsync(dln, sizeof(float) * d.P * d.D, dx + d.D, sizeof(float) * d.N * d.D, sizeof(float) * d.P * d.D, d.B,
                            hipMemcpyDeviceToDevice, st));
@@ -894,7 +902,7 @@ extern "C" long long dgvit_got_bf16_backward_scratch_bytes(const dgvit_config* c
 }
 
 extern "C" int dgvit_got_pack_weights_bf16(const dgvit_config* cfg, const float* const* params, unsigned short* wpack,
-                                           long long wpack_elems, void* stream) {
+                                           long long wpack_elems, int with_transposes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   Dims d;
   TRY(make_dims(cfg, 1, d));
@@ -910,6 +918,7 @@ extern "C" int dgvit_got_pack_weights_bf16(const dgvit_config* cfg, const float*
     TRY(cast_f32_bf16(lp[L_OUTW], lw + w.out, (long long)d.D * d.I, st));
     TRY(cast_f32_bf16(lp[L_FC1W], lw + w.fc1, (long long)d.M * d.D, st));
     TRY(cast_f32_bf16(lp[L_FC2W], lw + w.fc2, (long long)d.D * d.M, st));
+    if (!with_transposes) continue;
     TRY(transpose_cast_f32_bf16(lp[L_QKV], lw + w.qkvT, 3 * d.I, d.D, st));   // (3I, D) -> (D, 3I)
     TRY(transpose_cast_f32_bf16(lp[L_OUTW], lw + w.outT, d.D, d.I, st));      // (D, I)  -> (I, D)
     TRY(transpose_cast_f32_bf16(lp[L_FC1W], lw + w.fc1T, d.M, d.D, st));      // (M, D)  -> (D, M)
@@ -1043,7 +1052,7 @@ extern "C" int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* con
   if (scratch_bytes < s.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "bf16 backward scratch %lld < %lld bytes", scratch_bytes, s.total);
   DGVIT_CHECK_ARG((uintptr_t)workspace % 256 == 0 && (uintptr_t)scratch % 256 == 0, "bf16 path: workspace / scratch must be 256-byte aligned");
   const int np = P_L0 + DGVIT_PARAMS_PER_LAYER * d.L;
-  for (int i = 0; i < np; ++i) DGVIT_CHECK_ARG(params[i] && grads[i], "parameter/gradient %d is null", i);
+  for (int i = 0; i < np; ++i) DGVIT_CHECK_ARG(params[i], "parameter %d is null", i);   // grads[i] == NULL: frozen parameter
   const unsigned char* ws = (const unsigned char*)workspace;
   unsigned char* sc = (unsigned char*)scratch;
   const int T = (int)d.T;
@@ -1060,6 +1069,7 @@ extern "C" int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* con
   // dW (no x ni) and optionally db (no) from dY (T x no, row stride ldy) and X (T x ni, row stride ldx)
   auto wgrad = [&](const bf16_t* dY, int ldy, const bf16_t* X, int ldx, float* dW, float* db, int no, int ni) -> int {
     if (db) TRY(colsum_bf16(dY, ldy, db, part, T, no, st));
+    if (!dW) return DGVIT_OK;
     return wgrad_bf16_tn(dY, ldy, X, ldx, dW, no, ni, T, slabs, s.slab_floats, st);
   };
 
@@ -1121,7 +1131,8 @@ extern "C" int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* con
   if (dgoal)
     HIP_TRY(hipMemcpy2DAsync(dgoal, sizeof(float) * d.D, dx, sizeof(float) * d.N * d.D, sizeof(float) * d.D, d.B,
                              hipMemcpyDeviceToDevice, st));
-  TRY(colsum(dx, (long long)d.N * d.D, grads[P_POS], part, d.B, d.N * d.D, 0, st));
+  if (grads[P_POS]) TRY(colsum(dx, (long long)d.N * d.D, grads[P_POS], part, d.B, d.N * d.D, 0, st));
+  if (!grads[P_PW] && !grads[P_PB]) return DGVIT_OK;
   HIP_TRY(hipMemcpy2DAsync(dx2, sizeof(float) * d.P * d.D, dx + d.D, sizeof(float) * d.N * d.D, sizeof(float) * d.P * d.D, d.B,
                            hipMemcpyDeviceToDevice, st));
   float* patches32 = (float*)(sc + s.patches32);

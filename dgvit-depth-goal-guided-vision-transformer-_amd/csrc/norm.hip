@@ -219,10 +219,19 @@ int layernorm_fwd(const float* x, const float* gamma, const float* beta, float* 
 int layernorm_bwd_blocks(int T) { return T < 2048 ? (T + 3) / 4 : (T < 16384 ? 512 : 2048); }
 static int layernorm_bwd_blocks_f32(int T) { return T < 2048 ? (T + 3) / 4 : 512; }
 
+// partial is [nb][2][D]: one pass reduces both halves (stride 2*D), first D sums -> dgamma, next D -> dbeta;
+// a null dgamma / dbeta (frozen parameter) is skipped
+static int ln_param_grads(const float* partial, float* dgamma, float* dbeta, int D, int nb, hipStream_t stream) {
+  if (dgamma && dbeta) return reduce_slabs2(partial, dgamma, D, dbeta, 2ll * D, nb, 2ll * D, stream);
+  if (dgamma) return reduce_slabs(partial, dgamma, D, nb, 2ll * D, stream);
+  if (dbeta) return reduce_slabs(partial + D, dbeta, D, nb, 2ll * D, stream);
+  return DGVIT_OK;
+}
+
 // partial must hold layernorm_bwd_blocks(T) * 2 * D floats; dgamma/dbeta are written (not accumulated)
 int layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
                   float* dx, float* dgamma, float* dbeta, float* partial, int T, int D, int rs, hipStream_t stream) {
-  DGVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && partial, "layernorm_bwd: null pointer");
+  DGVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && partial, "layernorm_bwd: null pointer");
   DGVIT_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bwd: D=%d must be a multiple of 4, <= 1024", D);
   const int nb = layernorm_bwd_blocks_f32(T);
   const int nch = (D + 255) / 256;
@@ -235,14 +244,13 @@ int layernorm_bwd(const float* dy, const float* x, const float* mean, const floa
   else LNB(4);
 #undef LNB
   DGVIT_CHECK_LAUNCH("layernorm_bwd");
-  // partial is [nb][2][D]: one pass reduces both halves (stride 2*D), first D sums -> dgamma, next D -> dbeta
-  return reduce_slabs2(partial, dgamma, D, dbeta, 2ll * D, nb, 2ll * D, stream);
+  return ln_param_grads(partial, dgamma, dbeta, D, nb, stream);
 }
 
 // bf16 configuration: dy bf16; dx fp32 (+ optional bf16 copy dxb)
 int layernorm_bwd_bf16(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
                        float* dx, bf16_t* dxb, float* dgamma, float* dbeta, float* partial, int T, int D, int rs, hipStream_t stream) {
-  DGVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && partial, "layernorm_bwd_bf16: null pointer");
+  DGVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && partial, "layernorm_bwd_bf16: null pointer");
   DGVIT_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bwd_bf16: D=%d must be a multiple of 4, <= 1024", D);
   const int nb = layernorm_bwd_blocks(T);
   const int nch = (D + 255) / 256;
@@ -257,7 +265,7 @@ int layernorm_bwd_bf16(const bf16_t* dy, const float* x, const float* mean, cons
 #undef LNB
   profile_end(slot, stream);
   DGVIT_CHECK_LAUNCH("layernorm_bwd_bf16");
-  return reduce_slabs2(partial, dgamma, D, dbeta, 2ll * D, nb, 2ll * D, stream);
+  return ln_param_grads(partial, dgamma, dbeta, D, nb, stream);
 }
 
 int rmsnorm_fwd(const float* x, long long ldx, const float* g, float* y, int B, int D, hipStream_t stream) {
@@ -271,11 +279,11 @@ int rmsnorm_bwd_blocks(int B) { return B < 256 ? (B + 3) / 4 : 64; }
 
 int rmsnorm_bwd(const float* dy, const float* x, long long ldx, const float* g, float* dx, long long lddx, float* dg,
                 float* partial, int B, int D, hipStream_t stream) {
-  DGVIT_CHECK_ARG(dy && x && g && dx && dg && partial && B > 0 && D > 0 && D <= 4096, "rmsnorm_bwd: bad arguments");
+  DGVIT_CHECK_ARG(dy && x && g && dx && partial && B > 0 && D > 0 && D <= 4096, "rmsnorm_bwd: bad arguments");
   const int nb = rmsnorm_bwd_blocks(B);
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(256), 4 * D * sizeof(float), stream, dy, x, ldx, g, dx, lddx, partial, B, D);
   DGVIT_CHECK_LAUNCH("rmsnorm_bwd");
-  return reduce_slabs(partial, dg, D, nb, D, stream);
+  return dg ? reduce_slabs(partial, dg, D, nb, D, stream) : DGVIT_OK;   // dg == null: frozen gain
 }
 
 int colsum_blocks(int T) { return T < 1024 ? 1 : (T < 16384 ? 16 : 64); }

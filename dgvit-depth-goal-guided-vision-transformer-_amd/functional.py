@@ -57,6 +57,37 @@ def make_config(image, patch, dim, depth, heads, dim_head, mlp_dim) -> dgvit_con
 
 
 # ------------------------------------------------------------------------------------------------ encoder
+_N_NONPARAM_INPUTS = 6   # img, goal, cfg_tuple, keep, seed, need_grad precede *params in _GoTEncoder.apply
+
+
+def _flat_grads(params, needs, dev):
+    """Gradient tensors for the parameters autograd asks for, as views of ONE flat fp32 buffer laid out in parameter-table
+    order (4-float aligned slots, the layout of optim._Block and parallel.GradSync): autograd adopts them as .grad without
+    a copy.  Frozen parameters (``requires_grad`` off: ``needs[i]`` False) get None -- the C ABI then skips their
+    weight-gradient work.  The buffer is zero-filled so that the padding lanes between slots stay finite for whoever
+    consumes the flat buffer as a whole (Adam moments, all-reduce)."""
+    offs, off = [], 0
+    for p, need in zip(params, needs):
+        offs.append(off)
+        if need:
+            off += (p.numel() + 3) & ~3
+    flat = torch.zeros(off, dtype=torch.float32, device=dev) if off else None
+    return [flat[o:o + p.numel()].view_as(p) if need else None for o, p, need in zip(offs, params, needs)]
+
+
+def _grad_table(grads):
+    return (ctypes.c_void_p * len(grads))(*[0 if g is None else g.data_ptr() for g in grads])
+
+
+def _take_workspace(ctx, what):
+    """The forward's activation workspace is released by the first backward: a second one cannot be served."""
+    ws = ctx.ws
+    if ws is None:
+        raise DgvitError(f"{what}: backward called a second time; the fused encoder frees its activation workspace after "
+                         "the first backward (retain_graph=True is not supported) -- run the forward again")
+    return ws
+
+
 class _GoTEncoder(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, goal, cfg_tuple, keep, seed, need_grad, *params):
@@ -95,24 +126,20 @@ class _GoTEncoder(torch.autograd.Function):
     def backward(ctx, dfeat):
         lib = _lib.load()
         cfg = dgvit_config(*ctx.cfg_tuple)
+        ws = _take_workspace(ctx, "dgvit_got_backward")
         params = list(ctx.saved_tensors)
         dfeat = _dev(dfeat, "dfeat")
         B = ctx.batch
         dev = dfeat.device
         # all parameter gradients are views of ONE flat buffer: autograd adopts them as .grad without a copy, and
         # parallel.GradSync all-reduces the buffer in place (one large RCCL call instead of 70 small tensors)
-        sizes = [p.numel() for p in params]
-        offs = [0]
-        for n in sizes:
-            offs.append(offs[-1] + ((n + 3) & ~3))          # keep every view 16-byte aligned
-        flat = torch.empty(offs[-1], dtype=torch.float32, device=dev)
-        grads = [flat[o:o + n].view_as(p) for o, n, p in zip(offs, sizes, params)]
-        dgoal = torch.empty(B, cfg.dim, dtype=torch.float32, device=dev)
+        grads = _flat_grads(params, ctx.needs_input_grad[_N_NONPARAM_INPUTS:], dev)
+        dgoal = torch.empty(B, cfg.dim, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         nsc = lib.dgvit_got_backward_scratch_floats(ctypes.byref(cfg), B)
         scratch = torch.empty(nsc, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.dgvit_got_backward(ctypes.byref(cfg), _table(params), _table(grads), _ptr(dfeat), _ptr(dgoal), _ptr(ctx.ws),
-                                        ctx.ws.numel(), _ptr(scratch), nsc, B, ctx.keep, ctx.seed, _ptr(ctx.seed_dev), _stream())
+            rc = lib.dgvit_got_backward(ctypes.byref(cfg), _table(params), _grad_table(grads), _ptr(dfeat), _ptr(dgoal), _ptr(ws),
+                                        ws.numel(), _ptr(scratch), nsc, B, ctx.keep, ctx.seed, _ptr(ctx.seed_dev), _stream())
         _lib.check(rc, "dgvit_got_backward")
         ctx.ws = None
         return (None, dgoal, None, None, None, None, *grads)
@@ -156,6 +183,7 @@ class _CnnStack(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeat):
         lib = _lib.load()
+        ws = _take_workspace(ctx, "dgvit_cnn_backward")
         img, *params = ctx.saved_tensors
         dfeat = _dev(dfeat, "dfeat")
         B, H, W = img.shape
@@ -163,7 +191,7 @@ class _CnnStack(torch.autograd.Function):
         nsc = lib.dgvit_cnn_backward_scratch_floats(B, H, W)
         scratch = torch.empty(nsc, dtype=torch.float32, device=img.device)
         with torch.cuda.device(img.device):
-            rc = lib.dgvit_cnn_backward(_ptr(img), _table(params), _table(grads), _ptr(dfeat), _ptr(ctx.ws), ctx.ws.numel(),
+            rc = lib.dgvit_cnn_backward(_ptr(img), _table(params), _table(grads), _ptr(dfeat), _ptr(ws), ws.numel(),
                                         _ptr(scratch), nsc, B, H, W, _stream())
         _lib.check(rc, "dgvit_cnn_backward")
         ctx.ws = None
@@ -399,27 +427,87 @@ def op_attention_bwd_bf16(qkv, out, dout, lse, heads, dim_head=64):
 
 
 class Bf16Weights:
-    """bf16 copies of an encoder's GEMM weights in one arena (dgvit_got_pack_weights_bf16), re-packed only when a master
-    parameter has changed (tensor version counters)."""
+    """bf16 copies of an encoder's GEMM weights in one arena (dgvit_got_pack_weights_bf16).
+
+    The copies are re-packed from the fp32 masters before EVERY forward (on the forward's stream, so a captured HIP graph
+    replays the pack too).  Nothing cheaper is correct: fused optimiser steps, Polyak updates, ``param.data.copy_`` (the
+    reference's utils.soft_update / hard_update, utils.py:31-37) and collective broadcasts all write parameters without
+    touching autograd's version counters, so no host-side key can tell that a master has changed.  The pack is one HBM pass
+    over the GEMM weights (0.1 ms for the 85 M-parameter ViT-Base variant against a 20 ms forward); transposed copies, which
+    only the backward reads, are skipped under no_grad.
+
+    ``frozen=True`` (``GoT.freeze_bf16_weights()``: serving with weights that no longer change) packs once and reuses the
+    arena until ``invalidate()``; every in-tree writer of parameters (FlatAdam.step, soft_update, hard_update,
+    GradSync.broadcast_parameters, load_state_dict) invalidates, and a moved parameter (``.to()``) is detected by address."""
 
     def __init__(self):
         self.arena = None
-        self.key = None
+        self.frozen = False
+        self.generation = 0          # bumped by invalidate(); packed_generation lags behind it while the arena is stale
+        self._packed = None          # (generation, parameter addresses, with_transposes) of the arena's content
+        self.packs = 0               # number of pack launches (tests)
 
-    def get(self, cfg, params):
+    def invalidate(self):
+        self.generation += 1
+
+    def __getstate__(self):       # torch.save(module): the arena is a cache, not state
+        return {"frozen": self.frozen}
+
+    def __setstate__(self, state):
+        self.__init__()
+        self.frozen = bool(state.get("frozen", False))
+
+    def get(self, cfg, params, with_transposes=True):
         lib = _lib.load()
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        if self.arena is None or key != self.key or self.arena.device != params[0].device:
-            n = lib.dgvit_got_bf16_weight_elems(ctypes.byref(cfg))
-            if n < 0:
-                _lib.check(-1, "dgvit_got_bf16_weight_elems")
-            if self.arena is None or self.arena.numel() != n or self.arena.device != params[0].device:
-                self.arena = torch.empty(n, dtype=torch.bfloat16, device=params[0].device)
-            with torch.cuda.device(params[0].device):
-                rc = lib.dgvit_got_pack_weights_bf16(ctypes.byref(cfg), _table(params), _ptr(self.arena), n, _stream())
-            _lib.check(rc, "dgvit_got_pack_weights_bf16")
-            self.key = key
+        dev = params[0].device
+        key = (self.generation, tuple(p.data_ptr() for p in params))
+        if self.frozen and self.arena is not None and self.arena.device == dev and self._packed is not None \
+                and self._packed[:2] == key and (self._packed[2] or not with_transposes):
+            return self.arena
+        n = lib.dgvit_got_bf16_weight_elems(ctypes.byref(cfg))
+        if n < 0:
+            _lib.check(-1, "dgvit_got_bf16_weight_elems")
+        if self.arena is None or self.arena.numel() != n or self.arena.device != dev:
+            self.arena = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.dgvit_got_pack_weights_bf16(ctypes.byref(cfg), _table(params), _ptr(self.arena), n, int(with_transposes), _stream())
+        _lib.check(rc, "dgvit_got_pack_weights_bf16")
+        self._packed = (*key, bool(with_transposes))
+        self.packs += 1
+        if self.frozen:
+            reg = _frozen_registry()
+            for p in params:
+                reg[p] = self
         return self.arena
+
+
+_FROZEN_ARENAS = None   # parameter -> Bf16Weights holding a frozen copy of it (identity-keyed, weak)
+
+
+def _frozen_registry():
+    global _FROZEN_ARENAS
+    if _FROZEN_ARENAS is None:
+        from torch.utils.weak import WeakIdKeyDictionary
+        _FROZEN_ARENAS = WeakIdKeyDictionary()
+    return _FROZEN_ARENAS
+
+
+def notify_parameters_changed(objs):
+    """Tell the bf16 weight caches that fp32 masters were written behind autograd's back (see Bf16Weights).  ``objs``: a module,
+    or an iterable of modules and / or parameters."""
+    if isinstance(objs, torch.nn.Module):
+        objs = [objs]
+    reg = _frozen_registry()
+    for o in objs:
+        if isinstance(o, torch.nn.Module):
+            for sub in o.modules():
+                w = getattr(sub, "_bf16_weights", None)
+                if isinstance(w, Bf16Weights):
+                    w.invalidate()
+        else:
+            w = reg.get(o)
+            if w is not None:
+                w.invalidate()
 
 
 def op_wgrad_bf16(dy, x, want_bias=True):
@@ -456,7 +544,7 @@ class _GoTEncoderBf16(torch.autograd.Function):
         B = img.shape[0]
         if goal.shape != (B, cfg.dim):
             raise DgvitError(f"goal must be ({B}, {cfg.dim}), got {tuple(goal.shape)}")
-        wpack = weights.get(cfg, params)
+        wpack = weights.get(cfg, params, with_transposes=bool(need_grad))
         nws = lib.dgvit_got_bf16_workspace_bytes(ctypes.byref(cfg), B, int(need_grad))
         if nws < 0:
             _lib.check(-1, "dgvit_got_bf16_workspace_bytes")
@@ -478,21 +566,17 @@ class _GoTEncoderBf16(torch.autograd.Function):
     def backward(ctx, dfeat):
         lib = _lib.load()
         cfg = dgvit_config(*ctx.cfg_tuple)
+        ws = _take_workspace(ctx, "dgvit_got_backward_bf16")
         params = list(ctx.saved_tensors)
         dfeat = _dev(dfeat, "dfeat")
         B, dev = ctx.batch, dfeat.device
-        sizes = [p.numel() for p in params]
-        offs = [0]
-        for n in sizes:
-            offs.append(offs[-1] + ((n + 3) & ~3))
-        flat = torch.empty(offs[-1], dtype=torch.float32, device=dev)     # one flat gradient buffer (see _GoTEncoder.backward)
-        grads = [flat[o:o + n].view_as(p) for o, n, p in zip(offs, sizes, params)]
-        dgoal = torch.empty(B, cfg.dim, dtype=torch.float32, device=dev)
+        grads = _flat_grads(params, ctx.needs_input_grad[_N_NONPARAM_INPUTS + 1:], dev)   # one flat buffer (see _GoTEncoder.backward)
+        dgoal = torch.empty(B, cfg.dim, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         nsc = lib.dgvit_got_bf16_backward_scratch_bytes(ctypes.byref(cfg), B)
         scratch = torch.empty(nsc, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.dgvit_got_backward_bf16(ctypes.byref(cfg), _table(params), _ptr(ctx.wpack), _table(grads), _ptr(dfeat), _ptr(dgoal),
-                                             _ptr(ctx.img), _ptr(ctx.ws), ctx.ws.numel(), _ptr(scratch), nsc, B, ctx.keep, ctx.seed,
+            rc = lib.dgvit_got_backward_bf16(ctypes.byref(cfg), _table(params), _ptr(ctx.wpack), _grad_table(grads), _ptr(dfeat), _ptr(dgoal),
+                                             _ptr(ctx.img), _ptr(ws), ws.numel(), _ptr(scratch), nsc, B, ctx.keep, ctx.seed,
                                              _ptr(ctx.seed_dev), _stream())
         _lib.check(rc, "dgvit_got_backward_bf16")
         ctx.ws = ctx.wpack = ctx.img = None

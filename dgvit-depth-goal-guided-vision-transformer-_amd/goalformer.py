@@ -80,6 +80,11 @@ class Transformer(_Holder):
             for _ in range(depth)])
 
 
+def _weights_loaded(module, incompatible_keys):
+    """load_state_dict post-hook (a module-level function: the module must stay picklable, attention_imitating.py:199)."""
+    module._bf16_weights.invalidate()
+
+
 class GoT(nn.Module):
     """Goal-guided ViT encoder: (B, H, W) depth frames + (B, dim) goal embedding -> (B, dim) features."""
 
@@ -109,6 +114,28 @@ class GoT(nn.Module):
                      1 if pool == 'mean' else 0)
         self.compute_dtype = torch.float32
         self._bf16_weights = F_.Bf16Weights()
+        self.register_load_state_dict_post_hook(_weights_loaded)
+
+    def __deepcopy__(self, memo):
+        # the bf16 weight arena is a cache of THIS module's parameters: a copy (DRL.py:169 deep-copies the policy) starts its own
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = F_.Bf16Weights() if k == "_bf16_weights" else copy.deepcopy(v, memo)
+        new._bf16_weights.frozen = self._bf16_weights.frozen
+        return new
+
+    def freeze_bf16_weights(self, frozen: bool = True):
+        """bf16 configuration only.  By default the bf16 copies of the GEMM weights are re-packed from the fp32 masters before
+        every forward (nothing cheaper can see a fused optimiser step or a ``param.data.copy_``).  ``freeze_bf16_weights()``
+        declares that the weights no longer change (serving): the copies are packed once and reused.  Parameter writers of this
+        package (FlatAdam, soft_update, hard_update, GradSync.broadcast_parameters, load_state_dict) still invalidate them;
+        after any OTHER in-place write call ``freeze_bf16_weights()`` again (it drops the cached copies)."""
+        self._bf16_weights.frozen = bool(frozen)
+        self._bf16_weights.invalidate()
+        return self
 
     def set_compute_dtype(self, dtype):
         """torch.float32 (default: exact fp32 MFMA path) or torch.bfloat16 (BASELINE config 5: bf16 storage for the GEMM

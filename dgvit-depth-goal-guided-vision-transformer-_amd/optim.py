@@ -1,20 +1,25 @@
 """Flat-buffer optimiser step and Polyak target update for the DGViT networks.
 
 The reference calls ``torch.optim.Adam`` over ~70 tensors per network (DRL.py:126-168, 401-403, 412-414) and a
-per-parameter Python loop ``soft_update`` (utils.py:31-33).  Here the parameters of a network are re-homed into
-flat fp32 buffers (each ``nn.Parameter`` keeps its identity, its ``.data`` becomes a view), and both updates are
-one HBM-bound HIP kernel per buffer (``dgvit_adam_step`` / ``dgvit_soft_update``).
+per-parameter Python loop ``soft_update`` (utils.py:31-33).  Here the parameters of a network are re-homed ONCE into
+one flat fp32 buffer (its *home*: each ``nn.Parameter`` keeps its identity, its ``.data`` becomes a view), and both
+updates are one HBM-bound HIP kernel per contiguous run of that buffer (``dgvit_adam_step`` / ``dgvit_soft_update``).
 
-The fused encoder backward already delivers all encoder gradients as views of one flat buffer laid out in
-parameter-table order; when ``FlatAdam`` finds that layout it consumes the buffer in place, otherwise it gathers
-the gradients with one multi-tensor copy.
+There is one owner of parameter storage per module: ``flatten_parameters(module)`` creates (or returns) the module's
+home and ``FlatAdam`` adopts it, so an optimiser and a Polyak update on the same network share the same buffer.
+Layout of a home: for every ``GoT`` encoder inside the module its trainable parameters in the C ABI's table order --
+exactly the layout of the flat gradient buffer the fused encoder backward produces, which Adam then consumes in place --
+followed by all remaining parameters in ``parameters()`` order.  Two networks of the same architecture get the same
+layout, which is what the one-kernel ``soft_update`` needs.
 """
 import ctypes
-from typing import Iterable, List
+from typing import Iterable, List, Union
 
 import torch
+from torch.utils.weak import WeakIdKeyDictionary
 
 from . import _lib
+from . import functional as F_
 from .goalformer import GoT
 
 
@@ -26,158 +31,286 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-class _Block:
-    """A group of parameters living back to back (4-float aligned) in one flat buffer."""
+_HOME_OF = WeakIdKeyDictionary()   # parameter -> (home, index in home.params); keyed by identity (tensor == is elementwise)
 
-    def __init__(self, params: List[torch.nn.Parameter]):
+
+def _no_home():
+    return None
+
+
+class _Home:
+    """Parameters living back to back (4-float aligned slots) in one flat buffer, with room for Adam's moments."""
+
+    def __init__(self, params: List[torch.nn.Parameter], sections: List[int] = None):
+        # sections[i]: which GoT encoder's table parameter i belongs to (-1: none); Adam runs never straddle two sections, so
+        # the encoder run can pick up the fused backward's gradient buffer without a copy
+        self.sections = list(sections) if sections is not None else [-1] * len(params)
+        if not params:
+            raise ValueError("no parameters to flatten")
+        if not all(p.is_cuda for p in params):
+            raise _lib.DgvitError("flat parameter buffers need the module on a ROCm device first (call .to(device) before)")
         self.params = params
         self.offsets, off = [], 0
         for p in params:
             self.offsets.append(off)
             off += _al4(p.numel())
         self.numel = off
-        ref = params[0]
-        if not ref.is_cuda:
-            raise _lib.DgvitError("flat parameter buffers need the module on a ROCm device first (call .to(device) before)")
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=ref.device)
-        for p, o in zip(params, self.offsets):
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=params[0].device)   # zeros: padding lanes stay finite
+        for i, (p, o) in enumerate(zip(params, self.offsets)):
             v = self.flat[o:o + p.numel()].view_as(p)
             v.copy_(p.data)
             p.data = v
-        self.exp_avg = torch.zeros_like(self.flat)
-        self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.gflat = None
+            _HOME_OF[p] = (self, i)
+        self.exp_avg = self.exp_avg_sq = self.gflat = None
+        self.zero_copy_elems = self.copied_elems = 0   # gradient elements Adam consumed in place / had to gather (tests, tuning)
+        self.steps = [0] * len(params)          # per-parameter Adam step counts (torch keeps `state[p]["step"]`)
+        self.signature = tuple((tuple(p.shape), o) for p, o in zip(params, self.offsets))
+
+    def __deepcopy__(self, memo):
+        return None     # a copied module's parameters are fresh tensors: its home is rebuilt on first use
+
+    def __reduce__(self):
+        return (_no_home, ())   # torch.save(module): parameters are pickled as ordinary tensors, the home is rebuilt on use
 
     def intact(self) -> bool:
         base = self.flat.data_ptr()
         return all(p.data.data_ptr() == base + 4 * o for p, o in zip(self.params, self.offsets))
 
-    def gather_grads(self) -> torch.Tensor:
-        """The gradients as one flat tensor with this block's layout (zero copy when they already are)."""
-        g0 = self.params[0].grad
-        st = g0.untyped_storage().data_ptr()
-        o0 = g0.storage_offset()
-        if all(p.grad.untyped_storage().data_ptr() == st and p.grad.storage_offset() - o0 == o and p.grad.is_contiguous()
-               for p, o in zip(self.params, self.offsets)) and o0 % 4 == 0:
-            return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(g0.untyped_storage(), o0, (self.numel,))
+    def moments(self):
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.flat)
+            self.exp_avg_sq = torch.zeros_like(self.flat)
+        return self.exp_avg, self.exp_avg_sq
+
+    def grad_run(self, idx: List[int]) -> torch.Tensor:
+        """Gradients of the parameters ``idx`` (adjacent slots) as one flat tensor laid out like their slots: zero copy when
+        they already are views of one buffer with that layout (the fused encoder backward's), else one multi-tensor copy."""
+        lo = self.offsets[idx[0]]
+        hi = self.offsets[idx[-1]] + _al4(self.params[idx[-1]].numel())
+        g0 = self.params[idx[0]].grad
+        st, o0 = g0.untyped_storage().data_ptr(), g0.storage_offset()
+        if o0 % 4 == 0 and g0.data_ptr() % 16 == 0 and (o0 + hi - lo) * 4 <= g0.untyped_storage().nbytes() and all(
+                self.params[i].grad.untyped_storage().data_ptr() == st and self.params[i].grad.is_contiguous()
+                and self.params[i].grad.storage_offset() - o0 == self.offsets[i] - lo for i in idx):
+            self.zero_copy_elems += hi - lo
+            return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(g0.untyped_storage(), o0, (hi - lo,))
+        self.copied_elems += hi - lo
         if self.gflat is None:
             self.gflat = torch.zeros_like(self.flat)
-        views = [self.gflat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
-        torch._foreach_copy_(views, [p.grad for p in self.params])
-        return self.gflat
+        views = [self.gflat[self.offsets[i]:self.offsets[i] + self.params[i].numel()].view_as(self.params[i]) for i in idx]
+        torch._foreach_copy_(views, [self.params[i].grad for i in idx])
+        return self.gflat[lo:hi]
+
+
+def _layout(module: torch.nn.Module):
+    order, sections, taken, nsec = [], [], set(), 0
+    for sub in module.modules():
+        if isinstance(sub, GoT):
+            for p in sub.param_table():
+                if p.requires_grad and id(p) not in taken:
+                    order.append(p)
+                    sections.append(nsec)
+                    taken.add(id(p))
+            nsec += 1
+    for p in module.parameters():
+        if id(p) not in taken:
+            order.append(p)
+            sections.append(-1)
+            taken.add(id(p))
+    return order, sections
+
+
+def flatten_parameters(module: torch.nn.Module) -> torch.Tensor:
+    """Re-home ALL parameters of ``module`` into one flat buffer (see the module docstring for the layout) and return it;
+    a module that already has an intact home keeps it.  Call after ``.to(device)``; ``FlatAdam`` and ``soft_update`` do it
+    themselves when needed."""
+    return home_of(module).flat
+
+
+def home_of(module: torch.nn.Module) -> _Home:
+    h = getattr(module, "_dgvit_home", None)
+    lay, sections = _layout(module)
+    if isinstance(h, _Home) and len(h.params) == len(lay) and all(a is b for a, b in zip(h.params, lay)):
+        if h.intact():
+            return h
+        if h.exp_avg is not None:
+            raise _lib.DgvitError("parameter storage was replaced (e.g. by .to()) after optimiser state was built; rebuild the optimiser")
+    h = _Home(lay, sections)
+    module._dgvit_home = h
+    return h
 
 
 class FlatAdam:
-    """``torch.optim.Adam`` semantics (amsgrad=False) with one HIP kernel per flat parameter block.
+    """``torch.optim.Adam`` semantics (amsgrad=False) with one HIP kernel per contiguous run of a flat parameter buffer.
 
-    ``modules``: the networks to optimise.  Every ``GoT`` encoder inside becomes one block in parameter-table
-    order (matching the fused backward's gradient buffer); all remaining parameters that receive gradients form
-    one more block, built on the first ``step()``.  Parameters that never get a gradient are left alone, like
-    torch's optimisers do.  Build it after ``module.to(device)``.  ``capturable=True`` keeps the step counter in device
-    memory (like torch's ``capturable`` optimisers) so that ``step()`` can be recorded into a HIP graph.
+    ``params``: modules (all their parameters) and / or an iterable of parameters, like the reference's optimisers over
+    sub-sets of a network (DRL.py:107-111, 145-148).  As with torch's optimisers a parameter whose ``.grad`` is None at
+    ``step()`` is skipped (no moment update, its own step count does not advance), and a parameter that first receives a
+    gradient later starts its bias correction at 1 then.  Build it after ``module.to(device)``.  ``capturable=True`` keeps
+    the step counter in device memory (like torch's ``capturable`` optimisers) so that ``step()`` can be recorded into a HIP
+    graph; every replay must then see the same set of parameters with gradients.
     """
 
-    def __init__(self, modules: Iterable[torch.nn.Module], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+    def __init__(self, params: Union[torch.nn.Module, Iterable], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  capturable: bool = False):
         self.capturable, self._step_dev = bool(capturable), None
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
-        self.modules = list(modules) if not isinstance(modules, torch.nn.Module) else [modules]
-        self.step_count = 0
-        self.blocks: List[_Block] = []
-        taken = set()
+        items = [params] if isinstance(params, torch.nn.Module) else list(params)
+        self.modules = [m for m in items if isinstance(m, torch.nn.Module)]
+        chosen, seen = [], set()
         for m in self.modules:
-            for sub in m.modules():
-                if isinstance(sub, GoT):
-                    table = [p for p in sub.param_table() if p.requires_grad]
-                    if table and all(id(p) not in taken for p in table):
-                        self.blocks.append(_Block(table))
-                        taken.update(id(p) for p in table)
-        self._taken = taken
-        self._rest_built = False
-
-    def _all_params(self):
-        seen = set()
-        for m in self.modules:
+            home_of(m)
             for p in m.parameters():
                 if p.requires_grad and id(p) not in seen:
                     seen.add(id(p))
-                    yield p
+                    chosen.append(p)
+        loose = []
+        for p in items:
+            if isinstance(p, torch.nn.Module):
+                continue
+            if not isinstance(p, torch.nn.Parameter):
+                raise TypeError(f"FlatAdam: expected modules or parameters, got {type(p).__name__}")
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                chosen.append(p)
+                ent = _HOME_OF.get(p)
+                if ent is None or not ent[0].intact():
+                    loose.append(p)
+        if loose:
+            _Home(loose)               # parameters handed over one by one that no module home owns yet
+        self.params = chosen
+        self.step_count = 0
+
+    def _all_params(self):
+        return self.params
 
     def zero_grad(self, set_to_none: bool = True) -> None:
-        for p in self._all_params():
+        for p in self.params:
             if set_to_none:
                 p.grad = None
             elif p.grad is not None:
                 p.grad.zero_()
 
-    def _build_rest(self) -> None:
-        rest = [p for p in self._all_params() if id(p) not in self._taken and p.grad is not None]
-        if rest:
-            self.blocks.append(_Block(rest))
-            self._taken.update(id(p) for p in rest)
-        self._rest_built = True
+    def _runs(self):
+        """[(home, [param indices])]: maximal runs of adjacent slots whose parameters have a gradient and equal step counts."""
+        by_home = {}
+        for p in self.params:
+            if p.grad is None:
+                continue
+            ent = _HOME_OF.get(p)
+            if ent is None or not ent[0].intact():
+                raise _lib.DgvitError("FlatAdam: parameter storage was replaced (e.g. by .to() or deepcopy); rebuild the optimiser")
+            by_home.setdefault(id(ent[0]), (ent[0], []))[1].append(ent[1])
+        runs = []
+        for home, idx in by_home.values():
+            idx.sort()
+            cur = [idx[0]]
+            for a, b in zip(idx, idx[1:]):
+                if b == a + 1 and home.steps[b] == home.steps[a] and home.sections[b] == home.sections[a]:
+                    cur.append(b)
+                else:
+                    runs.append((home, cur))
+                    cur = [b]
+            runs.append((home, cur))
+        return runs
 
     @torch.no_grad()
     def step(self) -> None:
         lib = _lib.load()
-        if not self._rest_built:
-            self._build_rest()
+        runs = self._runs()
+        if not runs:
+            return
         self.step_count += 1
         step_ptr = ctypes.c_void_p(0)
         if self.capturable:
+            if len({home.steps[idx[0]] for home, idx in runs}) != 1:
+                raise _lib.DgvitError("FlatAdam(capturable=True): every parameter must receive a gradient on every step")
             if self._step_dev is None:
-                self._step_dev = torch.full((1,), self.step_count - 1, dtype=torch.int64, device=self.blocks[0].flat.device)
+                self._step_dev = torch.full((1,), runs[0][0].steps[runs[0][1][0]], dtype=torch.int64, device=runs[0][0].flat.device)
             self._step_dev += 1                      # a device op: replayed with the graph
             step_ptr = ctypes.c_void_p(self._step_dev.data_ptr())
-        for b in self.blocks:
-            if any(p.grad is None for p in b.params):
-                raise _lib.DgvitError("FlatAdam: a parameter of a flat block has no gradient this step")
-            if not b.intact():
-                raise _lib.DgvitError("FlatAdam: parameter storage was replaced (e.g. by .to()); rebuild the optimiser")
-            g = b.gather_grads()
-            with torch.cuda.device(b.flat.device):
-                rc = lib.dgvit_adam_step(ctypes.c_void_p(b.flat.data_ptr()), ctypes.c_void_p(g.data_ptr()),
-                                         ctypes.c_void_p(b.exp_avg.data_ptr()), ctypes.c_void_p(b.exp_avg_sq.data_ptr()), b.numel,
-                                         self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, step_ptr, _stream())
+        for home, idx in runs:
+            lo = home.offsets[idx[0]]
+            n = home.offsets[idx[-1]] + _al4(home.params[idx[-1]].numel()) - lo
+            g = home.grad_run(idx)
+            m, v = home.moments()
+            t = home.steps[idx[0]] + 1
+            for i in idx:
+                home.steps[i] = t
+            with torch.cuda.device(home.flat.device):
+                rc = lib.dgvit_adam_step(ctypes.c_void_p(home.flat.data_ptr() + 4 * lo), ctypes.c_void_p(g.data_ptr()),
+                                         ctypes.c_void_p(m.data_ptr() + 4 * lo), ctypes.c_void_p(v.data_ptr() + 4 * lo), n,
+                                         self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, t, step_ptr, _stream())
             _lib.check(rc, "dgvit_adam_step")
+        # the kernel wrote the parameters through raw pointers: no autograd version counter moved
+        F_.notify_parameters_changed(self.params)
+
+    def _homes(self):
+        out, seen = [], set()
+        for p in self.params:
+            ent = _HOME_OF.get(p)
+            if ent is not None and id(ent[0]) not in seen:
+                seen.add(id(ent[0]))
+                out.append(ent[0])
+        return out
 
     def state_dict(self):
+        """Per parameter (in the optimiser's parameter order): step count and both moments, like torch.optim.Adam's state."""
+        state = []
+        for p in self.params:
+            home, i = _HOME_OF[p]
+            o, n = home.offsets[i], p.numel()
+            if home.exp_avg is None or home.steps[i] == 0:
+                state.append(None)
+            else:
+                state.append({"step": home.steps[i], "exp_avg": home.exp_avg[o:o + n].view_as(p).clone(),
+                              "exp_avg_sq": home.exp_avg_sq[o:o + n].view_as(p).clone()})
         return {"step": self.step_count, "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
-                "exp_avg": [b.exp_avg.clone() for b in self.blocks], "exp_avg_sq": [b.exp_avg_sq.clone() for b in self.blocks]}
+                "state": state}
 
     def load_state_dict(self, sd) -> None:
-        if len(sd["exp_avg"]) != len(self.blocks):
-            raise ValueError("optimizer state does not match the parameter blocks (run one step first to build them)")
+        if len(sd["state"]) != len(self.params):
+            raise ValueError("optimizer state does not match this optimiser's parameters")
         self.step_count = int(sd["step"])
-        for b, m, v in zip(self.blocks, sd["exp_avg"], sd["exp_avg_sq"]):
-            b.exp_avg.copy_(m)
-            b.exp_avg_sq.copy_(v)
+        for p, st in zip(self.params, sd["state"]):
+            home, i = _HOME_OF[p]
+            o, n = home.offsets[i], p.numel()
+            m, v = home.moments()
+            if st is None:
+                home.steps[i] = 0
+                m[o:o + n].zero_()
+                v[o:o + n].zero_()
+            else:
+                home.steps[i] = int(st["step"])
+                m[o:o + n].view_as(p).copy_(st["exp_avg"])
+                v[o:o + n].view_as(p).copy_(st["exp_avg_sq"])
+        if self._step_dev is not None:
+            self._step_dev.fill_(max((_HOME_OF[p][0].steps[_HOME_OF[p][1]] for p in self.params), default=0))
 
 
-def flatten_parameters(module: torch.nn.Module) -> torch.Tensor:
-    """Re-home ALL parameters of ``module`` (in ``parameters()`` order) into one flat buffer; returns it and
-    remembers it on the module for ``soft_update``.  Call after ``.to(device)`` and before building optimisers."""
-    blk = _Block(list(module.parameters()))
-    module._dgvit_flat = blk
-    return blk.flat
+def _flat_pair(target, source):
+    tb, sb = home_of(target), home_of(source)
+    if tb.signature != sb.signature:
+        raise _lib.DgvitError("soft_update: target and source networks do not have the same parameter layout")
+    return tb, sb
 
 
 @torch.no_grad()
 def soft_update(target: torch.nn.Module, source: torch.nn.Module, tau: float) -> None:
-    """target <- target*(1-tau) + source*tau (utils.py:31-33).  One HIP kernel when both modules went through
-    ``flatten_parameters``; otherwise the reference's per-parameter loop."""
-    tb, sb = getattr(target, "_dgvit_flat", None), getattr(source, "_dgvit_flat", None)
-    if tb is not None and sb is not None and tb.numel == sb.numel and tb.intact() and sb.intact():
-        lib = _lib.load()
-        with torch.cuda.device(tb.flat.device):
-            rc = lib.dgvit_soft_update(ctypes.c_void_p(tb.flat.data_ptr()), ctypes.c_void_p(sb.flat.data_ptr()), tb.numel, float(tau),
-                                       _stream())
-        _lib.check(rc, "dgvit_soft_update")
-        return
-    for tp, sp in zip(target.parameters(), source.parameters()):
-        tp.data.mul_(1.0 - tau).add_(sp.data, alpha=tau)
+    """target <- target*(1-tau) + source*tau (utils.py:31-33) as ONE HIP kernel over the two networks' flat buffers (both are
+    flattened on first use; an optimiser built on either keeps working because it adopts the same home)."""
+    tb, sb = _flat_pair(target, source)
+    lib = _lib.load()
+    with torch.cuda.device(tb.flat.device):
+        rc = lib.dgvit_soft_update(ctypes.c_void_p(tb.flat.data_ptr()), ctypes.c_void_p(sb.flat.data_ptr()), tb.numel, float(tau),
+                                   _stream())
+    _lib.check(rc, "dgvit_soft_update")
+    F_.notify_parameters_changed(target)
 
 
+@torch.no_grad()
 def hard_update(target: torch.nn.Module, source: torch.nn.Module) -> None:
-    """utils.py:35-37."""
-    soft_update(target, source, 1.0)
+    """target <- source (utils.py:35-37): one device copy of the flat buffer."""
+    tb, sb = _flat_pair(target, source)
+    tb.flat.copy_(sb.flat)
+    F_.notify_parameters_changed(target)

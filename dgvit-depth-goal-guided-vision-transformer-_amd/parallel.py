@@ -16,10 +16,15 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, modules: Iterable[torch.nn.Module], process_group=None, bucket_bytes: int = 64 << 20):
+    def __init__(self, modules: Iterable[torch.nn.Module], process_group=None, bucket_bytes: int = 64 << 20,
+                 force_collective: bool = False):
+        """``force_collective``: issue the all-reduce even in a world of one rank (a 1-rank RCCL group reduces a buffer onto
+        itself) -- lets a single-GPU box exercise the exact code path the 8-GPU run takes."""
         self.params: List[torch.nn.Parameter] = []
+        self.modules = list(modules)
+        self.force_collective = bool(force_collective)
         seen = set()
-        for m in modules:
+        for m in self.modules:
             for p in m.parameters():
                 if p.requires_grad and id(p) not in seen:
                     seen.add(id(p))
@@ -34,10 +39,23 @@ class GradSync:
 
     def broadcast_parameters(self, src: int = 0) -> None:
         """Make every rank start from rank `src`'s weights (DRL.py builds nets from a per-process seed)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("GradSync: torch.distributed is not initialised")
+        from .optim import _HOME_OF
+        done = set()
         for p in self.params:
-            dist.broadcast(p.data, src=src, group=self.group)
+            ent = _HOME_OF.get(p)
+            if ent is not None and ent[0].intact():          # a flattened network travels as ONE buffer
+                if id(ent[0]) not in done:
+                    done.add(id(ent[0]))
+                    dist.broadcast(ent[0].flat, src=src, group=self.group)
+            else:
+                dist.broadcast(p.data, src=src, group=self.group)
+        # `.data` / flat-buffer writes do not move autograd's version counters: tell the bf16 weight caches
+        from . import functional as F_
+        F_.notify_parameters_changed(self.modules)
 
     def zero_grad(self) -> None:
         """Drop the gradients (set to None): the next backward's tensors are adopted as .grad without any
@@ -73,8 +91,10 @@ class GradSync:
         if self._last_numel == 0:
             raise RuntimeError("GradSync: no parameter has a gradient; call after backward()")
         w = self.world
-        if w == 1:
+        if w == 1 and not self.force_collective:
             return
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("GradSync: torch.distributed is not initialised")
         handles, bufs = [], list(shared)
         small = None
         if loose:

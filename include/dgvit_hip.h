@@ -21,7 +21,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define DGVIT_ABI_VERSION 4
+#define DGVIT_ABI_VERSION 5
 
 /* error codes */
 #define DGVIT_OK 0
@@ -31,6 +31,9 @@ extern "C" {
 #define DGVIT_ERR_WORKSPACE (-4)
 
 int dgvit_abi_version(void);
+/* sizeof(dgvit_config) as this library was compiled: a host binding checks its own struct against it before the first call
+ * (a struct one field short makes the library read past its end) */
+int dgvit_config_size(void);
 const char* dgvit_last_error(void);
 /* number of visible HIP devices (<0 on error); does not create a context */
 int dgvit_device_count(void);
@@ -89,6 +92,8 @@ int dgvit_got_forward(const dgvit_config* cfg, const float* const* params, const
 
 /* Gradient of dgvit_got_forward (what autograd derives for GoalFormer.py:156-171).
  *   dfeat (B, D) -> grads[] (same table order as params, each written, not accumulated), dgoal (B, D).
+ * A NULL entry of grads[] marks a frozen parameter (requires_grad off, e.g. the heads-only optimiser of DRL.py:145-148 with the
+ * encoder frozen): its weight-gradient GEMM / reduction is skipped.
  * `workspace` is the buffer the matching forward (save_for_backward=1) filled; same dropout_keep/seed. */
 int dgvit_got_backward(const dgvit_config* cfg, const float* const* params, float* const* grads, const float* dfeat,
                        float* dgoal, const float* workspace, long long workspace_floats, float* scratch,
@@ -226,8 +231,11 @@ int dgvit_soft_update(float* target, const float* source, long long n, float tau
  *   workspace: dgvit_got_bf16_workspace_bytes BYTES, 256-byte aligned.
  * -------------------------------------------------------------------------------------------- */
 long long dgvit_got_bf16_weight_elems(const dgvit_config* cfg);
+/* with_transposes == 0 fills only the (out, in) copies the forward reads (inference); != 0 also the transposes the backward's
+ * data-gradient GEMMs read.  The library keeps no state: call it (on the stream of the forward) whenever the fp32 masters may
+ * have changed -- the in-tree host re-packs before every forward. */
 int dgvit_got_pack_weights_bf16(const dgvit_config* cfg, const float* const* params, unsigned short* wpack,
-                                long long wpack_elems, void* stream);
+                                long long wpack_elems, int with_transposes, void* stream);
 long long dgvit_got_bf16_workspace_bytes(const dgvit_config* cfg, int batch, int save_for_backward);
 int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* const* params, const unsigned short* wpack, const float* img,
                            const float* goal, float* feat, void* workspace, long long workspace_bytes, int batch,

@@ -222,6 +222,14 @@ def case_cnn(name, kind, batch, seed, image=(128, 160)):
         mean, log_std = m([img, pstate])
         loss = (mean ** 2).mean() + (log_std ** 2).mean()
         out["mean"], out["log_std"] = mean.detach().numpy(), log_std.detach().numpy()
+        # sample() (got_sac_network.py:303-316) under a fixed torch seed, with the N(0,1) draw it consumed
+        torch.manual_seed(seed)
+        action, log_prob, tmean = m.sample([img, pstate])
+        torch.manual_seed(seed)
+        eps = torch.randn(batch, 2)
+        assert torch.allclose(action, torch.tanh(mean + log_std.exp() * eps), atol=1e-6), "noise stream mismatch"
+        out["noise"], out["action"] = eps.numpy(), action.detach().numpy()
+        out["log_prob"], out["tanh_mean"] = log_prob.detach().numpy(), tmean.detach().numpy()
     loss.backward()
     out["loss"] = np.array(loss.item())
     grad_summary(m, out, "g")

@@ -36,7 +36,7 @@ def test_library_exports_every_header_symbol(amd):
         assert hasattr(lib, name), f"libdgvit_hip.so does not export {name}"
         assert name in _lib.SIGNATURES, f"ctypes binding has no signature for {name}"
     assert sorted(_lib.SIGNATURES) == declared, "binding and header disagree"
-    assert lib.dgvit_abi_version() == 4
+    assert lib.dgvit_abi_version() == 5
 
 
 def test_size_queries_and_validation_without_gpu(amd):
@@ -156,3 +156,22 @@ def test_bf16_size_queries_and_host_switch_without_gpu(amd):
         m(torch.rand(2, 84, 84), torch.rand(2, 64))
     import copy
     assert copy.deepcopy(m).compute_dtype == torch.bfloat16
+
+
+def test_integration_md_binding_snippet_matches_the_library(amd):
+    """INTEGRATION.md's C-ABI snippet is what a host author copies: its dgvit_config must have the library's size (round 1
+    documented 9 of the 10 fields, which makes the library read pool_mean past the end of the caller's struct), its
+    argtypes must agree with the in-tree binding, and its example constructor call must fill every field."""
+    import ctypes
+    import re
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"class dgvit_config\(ctypes\.Structure\):\n\s+_fields_ = \[\(n, ctypes\.c_int\) for n in \(([^)]*)\)\]", text)
+    assert m, "INTEGRATION.md no longer holds the dgvit_config snippet"
+    names = [n.strip().strip('"') for n in m.group(1).split(",") if n.strip()]
+    from dgvit_amd import _lib
+    assert names == [f[0] for f in _lib.dgvit_config._fields_]
+    lib = amd.load_library()
+    assert lib.dgvit_config_size() == 4 * len(names) == ctypes.sizeof(_lib.dgvit_config)
+    call = re.search(r"cfg = dgvit_config\(([^)]*)\)", text)
+    assert call and len(call.group(1).split(",")) == len(names), "the example dgvit_config(...) call must pass every field"
+    assert f"dgvit_abi_version() == {_lib.ABI_VERSION}" in text

@@ -281,8 +281,11 @@ def test_flat_adam_matches_torch_adam(amd):
             mean, log_std = m([img, pstate])
             ((mean ** 2).mean() + (log_std ** 2).mean() * (it + 1)).backward()
             o.step()
-    blk = oa.blocks[0]
-    assert blk.gflat is None, "encoder gradients should have been consumed in place (zero copy)"
+    from dgvit_amd.optim import home_of
+    home = home_of(a)
+    enc = sum((p.numel() + 3) & ~3 for p in a.trans.param_table())
+    assert home.zero_copy_elems == 3 * enc, "encoder gradients should have been consumed in place (zero copy) on every step"
+    assert home.copied_elems < 3 * 40000, "only the head gradients are gathered"
     for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
     assert torch.equal(a.trans.cls_token, b.trans.cls_token)     # never gets a gradient: untouched by both
@@ -461,7 +464,6 @@ def test_graphed_training_step(amd):
         tgt = copy.deepcopy(model)
         flatten_parameters(tgt)
         opt = FlatAdam([model], lr=1e-3, capturable=True)
-        flatten_parameters(model) if False else None
 
         def step():
             opt.zero_grad(set_to_none=True)

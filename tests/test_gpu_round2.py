@@ -1,0 +1,560 @@
+"""GPU tests added in round 2 for the holes the round-1 review named:
+  * bf16 configuration + writers that bypass autograd's version counters (FlatAdam, soft_update, captured graphs);
+  * GoTPolicy.sample / GaussianPolicy.sample value checks against the reference's own (action, log_prob) with its noise injected;
+  * out-of-bounds canaries around every caller-sized buffer of the C ABI (GPU ASAN does not exist on this pool);
+  * the RCCL ("nccl") branch of GradSync on a one-rank group;
+  * frozen parameters (needs_input_grad), a second backward, FlatAdam on parameter sub-sets, FlatAdam + soft_update on one network.
+"""
+import copy
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import O, load_fixture, fixture_cfg  # noqa: E402
+
+OUT_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import dgvit_amd
+    dgvit_amd.load_library()
+    assert torch.cuda.is_available()
+    return dgvit_amd
+
+
+def _load_state(module, params):
+    module.load_state_dict(params, strict=True)
+    return module.cuda()
+
+
+def _small_got(amd, seed=3, depth=2, dim=64, heads=2, mlp=256):
+    torch.manual_seed(seed)
+    return amd.GoT(image_size=(48, 48), patch_size=(12, 12), num_classes=2, dim=dim, depth=depth, heads=heads, mlp_dim=mlp,
+                   channels=1).cuda()
+
+
+# ------------------------------------------------------------------------------------------------ bf16 + raw parameter writers
+def _fresh_bf16_features(amd, like, img, goal):
+    """Features of a freshly constructed bf16 module that strict-loads ``like``'s current state_dict (its pack happens now)."""
+    fresh = type(like)(image_size=(48, 48), patch_size=(12, 12), num_classes=2, dim=like._cfg[4], depth=like._cfg[5], heads=like._cfg[6],
+                       mlp_dim=like._cfg[8], channels=1).cuda()
+    fresh.load_state_dict(like.state_dict(), strict=True)
+    fresh.eval().set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        return fresh(img, goal)
+
+
+def test_bf16_flat_adam_steps_reach_the_gemm_weights(amd):
+    """Round-1 bug: FlatAdam writes parameters from a HIP kernel through raw pointers (no autograd version bump), and the bf16
+    weight copies were keyed on version counters, so every encoder GEMM kept using the step-0 weights.  After 3 steps the
+    eval-mode features must be bit-equal to those of a fresh bf16 module loaded with the updated state_dict, and must have
+    moved away from the step-0 features."""
+    from dgvit_amd.optim import FlatAdam
+    m = _small_got(amd).eval().set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(0)
+    img, goal = torch.rand(6, 48, 48, generator=g).cuda(), torch.randn(6, 64, generator=g).cuda()
+    tgt = torch.randn(6, 64, generator=g).cuda()
+    with torch.no_grad():
+        f0 = m(img, goal).clone()
+    opt = FlatAdam([m], lr=1e-2)
+    for _ in range(3):
+        opt.zero_grad()
+        ((m(img, goal) - tgt) ** 2).mean().backward()
+        opt.step()
+    with torch.no_grad():
+        f3 = m(img, goal)
+    assert torch.equal(f3, _fresh_bf16_features(amd, m, img, goal)), "bf16 GEMM weights are stale after FlatAdam.step()"
+    assert (f3 - f0).abs().max().item() > 1e-2, "features did not move: the optimiser's writes never reached the bf16 copies"
+    # frozen (serving) mode: packed once, reused, and still invalidated by FlatAdam
+    m.freeze_bf16_weights()
+    with torch.no_grad():
+        m(img, goal); n0 = m._bf16_weights.packs
+        m(img, goal); m(img, goal)
+        assert m._bf16_weights.packs == n0, "frozen weights must not be re-packed per forward"
+    opt.zero_grad()
+    ((m(img, goal) - tgt) ** 2).mean().backward()
+    opt.step()
+    with torch.no_grad():
+        f4 = m(img, goal)
+    assert m._bf16_weights.packs > n0
+    assert torch.equal(f4, _fresh_bf16_features(amd, m, img, goal))
+
+
+def test_bf16_target_tracks_soft_and_hard_update(amd):
+    """A bf16 target network must follow flat soft_update / hard_update AND the reference's own ``param.data.copy_`` loop
+    (utils.py:31-37), none of which moves a version counter."""
+    from dgvit_amd.optim import soft_update, hard_update
+    src = _small_got(amd, seed=1).eval()
+    tgt = _small_got(amd, seed=2).eval().set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(1)
+    img, goal = torch.rand(4, 48, 48, generator=g).cuda(), torch.randn(4, 64, generator=g).cuda()
+    with torch.no_grad():
+        f0 = tgt(img, goal).clone()
+    soft_update(tgt, src, 0.5)
+    with torch.no_grad():
+        f1 = tgt(img, goal).clone()
+    assert torch.equal(f1, _fresh_bf16_features(amd, tgt, img, goal))
+    assert (f1 - f0).abs().max().item() > 1e-2
+    for tp, sp in zip(tgt.parameters(), src.parameters()):       # the reference's loop, verbatim semantics
+        tp.data.copy_(tp.data * 0.5 + sp.data * 0.5)
+    with torch.no_grad():
+        f2 = tgt(img, goal).clone()
+    assert torch.equal(f2, _fresh_bf16_features(amd, tgt, img, goal))
+    assert (f2 - f1).abs().max().item() > 1e-3
+    hard_update(tgt, src)
+    with torch.no_grad():
+        f3 = tgt(img, goal)
+    for tp, sp in zip(tgt.parameters(), src.parameters()):
+        assert torch.equal(tp, sp)
+    assert torch.equal(f3, _fresh_bf16_features(amd, src, img, goal))
+
+
+def test_bf16_captured_training_step_repacks_inside_the_graph(amd):
+    """A bf16 training step captured into a HIP graph: the weight pack is part of the graph, so replays train on fresh weights."""
+    from dgvit_amd.optim import FlatAdam
+    base = _small_got(amd, seed=5).eval().set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(2)
+    img, goal = torch.rand(4, 48, 48, generator=g).cuda(), torch.randn(4, 64, generator=g).cuda()
+    tgt = torch.randn(4, 64, generator=g).cuda()
+
+    def make(model):
+        opt = FlatAdam([model], lr=1e-2, capturable=True)
+
+        def step():
+            opt.zero_grad()
+            loss = ((model(img, goal) - tgt) ** 2).mean()
+            loss.backward()
+            opt.step()
+            return loss.detach()
+        return step
+    ma, mb = copy.deepcopy(base), copy.deepcopy(base)
+    sa, sb = make(ma), make(mb)
+    gs = amd.GraphedStep(sb, warmup=2)
+    for _ in range(2):
+        sa()
+    for _ in range(3):
+        la, lb = sa(), gs()
+    torch.cuda.synchronize()
+    assert abs(la.item() - lb.item()) <= 1e-5 * max(1.0, abs(la.item()))
+    for (k, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------------ sample(): values, not shapes
+class _InjectedNoise:
+    """Normal.rsample replaced by mean + std * eps with the reference run's own eps (its CPU generator stream cannot be
+    reproduced on the device), exactly what got_sac_network.py:242 computes."""
+
+    def __init__(self, eps):
+        self.eps, self.orig = eps, None
+
+    def __enter__(self):
+        from torch.distributions import Normal
+        self.orig = Normal.rsample
+        eps = self.eps
+        Normal.rsample = lambda self_, sample_shape=torch.Size(): self_.loc + self_.scale * eps.to(self_.loc.device)
+        return self
+
+    def __exit__(self, *a):
+        from torch.distributions import Normal
+        Normal.rsample = self.orig
+
+
+@pytest.mark.parametrize("name", ["policy_native_shipped", "policy_native_small", "policy_c2"])
+def test_policy_sample_values_match_reference(amd, name):
+    """GoTPolicy.sample (got_sac_network.py:238-251): action, log_prob and tanh(mean) equal the reference's with its noise
+    injected; independently, log_prob is re-derived from the returned action through the oracle's formula."""
+    fx = load_fixture(name)
+    cfg = fixture_cfg(fx)
+    batch, seed = int(fx["meta/batch"]), int(fx["meta/seed"])
+    m = amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, image_size=cfg.image, patch_size=cfg.patch)
+    m = _load_state(m, O.make_params(O.policy_param_spec(cfg), seed)).eval().to("cuda")
+    img, pstate, _, _ = O.make_inputs(cfg, batch, seed)
+    with _InjectedNoise(torch.from_numpy(fx["noise"])):
+        action, log_prob, tmean = m.sample([img.cuda(), pstate.cuda()])
+    np.testing.assert_allclose(action.detach().cpu().numpy(), fx["action"], rtol=0, atol=OUT_TOL)
+    np.testing.assert_allclose(log_prob.detach().cpu().numpy(), fx["log_prob"], rtol=0, atol=5e-4)
+    np.testing.assert_allclose(tmean.detach().cpu().numpy(), fx["tanh_mean"], rtol=0, atol=OUT_TOL)
+    # un-patched sample(): recover x_t = atanh(action) and evaluate the tanh-Gaussian density on the oracle's mean / log_std
+    torch.manual_seed(seed)
+    a2, lp2, _ = m.sample([img.cuda(), pstate.cuda()])
+    rm, rl = O.policy_forward(O.make_params(O.policy_param_spec(cfg), seed), img, pstate, cfg)
+    y = a2.detach().cpu().double().clamp(-1 + 1e-7, 1 - 1e-7)
+    x_t = torch.atanh(y)
+    std = rl.double().exp()
+    ref = (-((x_t - rm.double()) ** 2) / (2 * std ** 2) - rl.double() - 0.5 * np.log(2 * np.pi) - torch.log(1 - y ** 2 + 1e-6)).sum(1, keepdim=True)
+    ok = (y.abs() < 0.999).all(dim=1)          # atanh is ill-conditioned next to +-1
+    assert ok.any()
+    np.testing.assert_allclose(lp2.detach().cpu().numpy()[ok.numpy()], ref.numpy()[ok.numpy()], rtol=0, atol=5e-3)
+
+
+def test_cnn_gaussian_policy_sample_values_match_reference(amd):
+    """GaussianPolicy.sample (got_sac_network.py:310-321) against the reference's own action / log_prob."""
+    fx = load_fixture("cnn_policy_native")
+    image = tuple(int(v) for v in fx["meta/image"])
+    batch, seed = int(fx["meta/batch"]), int(fx["meta/seed"])
+    m = _load_state(amd.GaussianPolicy(2, 2), O.make_params(O.cnn_policy_param_spec(), seed)).to("cuda")
+    img, pstate, _, _ = (t.cuda() for t in O.make_inputs(O.GoTConfig(image=image), batch, seed))
+    with _InjectedNoise(torch.from_numpy(fx["noise"])):
+        action, log_prob, tmean = m.sample([img, pstate])
+    np.testing.assert_allclose(action.detach().cpu().numpy(), fx["action"], rtol=0, atol=OUT_TOL)
+    np.testing.assert_allclose(log_prob.detach().cpu().numpy(), fx["log_prob"], rtol=0, atol=5e-4)
+    np.testing.assert_allclose(tmean.detach().cpu().numpy(), fx["tanh_mean"], rtol=0, atol=OUT_TOL)
+
+
+def test_sac_actor_loss_through_product_sample(amd):
+    """The actor loss of DRL.py:405-410 with log_pi taken from the product's sample() (round 1 re-derived it in the test)."""
+    fx = load_fixture("sac_c2")
+    cfg = fixture_cfg(fx)
+    batch, seed = int(fx["meta/batch"]), int(fx["meta/seed"])
+    kw = dict(image_size=cfg.image, patch_size=cfg.patch)
+    pol = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, **kw), O.make_params(O.policy_param_spec(cfg), seed)).eval().to("cuda")
+    crt = _load_state(amd.GoTQNetwork(2, 2, cfg.depth, cfg.heads, cfg.dim, **kw), O.make_params(O.qnet_param_spec(cfg), seed + 1)).eval()
+    img, pstate, _, _ = (t.cuda() for t in O.make_inputs(cfg, batch, seed))
+    with _InjectedNoise(torch.from_numpy(fx["noise"])):
+        pi, log_pi, _ = pol.sample([img, pstate])
+    np.testing.assert_allclose(pi.detach().cpu().numpy(), fx["pi"], rtol=0, atol=OUT_TOL)
+    np.testing.assert_allclose(log_pi.detach().cpu().numpy(), fx["log_pi"], rtol=0, atol=5e-4)
+    q1p, q2p = crt([img, pstate, pi])
+    loss = ((0.2 * log_pi) - torch.min(q1p, q2p)).mean()
+    np.testing.assert_allclose(loss.item(), float(fx["policy_loss"]), rtol=2e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ out-of-bounds canaries
+GUARD = 4096          # guard elements in front of and behind every buffer
+PATTERN = 0x7FC0DEAD  # a NaN with a recognisable payload: any write, even of a NaN, changes the bits
+
+
+class Guarded:
+    """payload of `n` elements of `dtype` between two guard zones filled with PATTERN; `t` is the payload view."""
+
+    def __init__(self, n, dtype=torch.float32, fill=None):
+        isz = torch.empty(0, dtype=dtype).element_size()
+        gbytes = GUARD * 4
+        nbytes = (n * isz + 255) // 256 * 256
+        self.raw = torch.empty(gbytes + nbytes + gbytes, dtype=torch.uint8, device="cuda")
+        assert self.raw.data_ptr() % 256 == 0
+        self.raw.view(torch.int32).fill_(PATTERN)
+        self.t = self.raw[gbytes:gbytes + n * isz].view(dtype)
+        self.lo, self.hi = self.raw[:gbytes].view(torch.int32), self.raw[gbytes + n * isz:].view(torch.uint8)
+        self.hi_ref = self.hi.clone()
+        if fill is not None:
+            self.t.copy_(fill)
+
+    def check(self, what):
+        assert bool((self.lo == PATTERN).all()), f"{what}: wrote in FRONT of the buffer"
+        assert torch.equal(self.hi, self.hi_ref), f"{what}: wrote BEHIND the buffer"
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+CANARY_SHAPES = [
+    # (image, patch, dim, depth, heads, dim_head, mlp, batch): ragged token counts, widths that are not tile multiples
+    ((84, 84), (12, 12), 64, 2, 2, 64, 256, 3),
+    ((36, 60), (12, 12), 36, 1, 3, 32, 100, 5),
+    ((84, 84), (6, 6), 128, 1, 2, 64, 388, 2),     # N = 197
+    ((24, 24), (24, 24), 8, 2, 1, 64, 12, 7),      # N = 2, tiny everything
+]
+
+
+@pytest.mark.parametrize("shape", CANARY_SHAPES)
+def test_canaries_encoder_fp32(amd, shape):
+    """dgvit_got_forward / dgvit_got_backward with every caller-sized buffer (workspace, scratch, feat, dgoal, gradients)
+    fenced by guard zones: the size queries must cover everything the kernels write."""
+    from dgvit_amd import _lib
+    lib = _lib.load()
+    image, patch, dim, depth, heads, dh, mlp, B = shape
+    torch.manual_seed(0)
+    m = amd.GoT(image_size=image, patch_size=patch, num_classes=2, dim=dim, depth=depth, heads=heads, mlp_dim=mlp, channels=1,
+                dim_head=dh).cuda()
+    cfg = _lib.dgvit_config(*m._cfg)
+    params = [p.detach().contiguous() for p in m.param_table()]
+    table = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+    img, goal = torch.rand(B, *image, device="cuda"), torch.randn(B, dim, device="cuda")
+    for save in (0, 1):
+        nws = lib.dgvit_got_workspace_floats(ctypes.byref(cfg), B, save)
+        ws, feat = Guarded(nws), Guarded(B * dim)
+        rc = lib.dgvit_got_forward(ctypes.byref(cfg), table, _p(img), _p(goal), _p(feat.t), _p(ws.t), nws, B, save, 0.9, 1234, None, _st())
+        _lib.check(rc, "dgvit_got_forward")
+        torch.cuda.synchronize()
+        ws.check(f"forward workspace (save={save})"); feat.check("feat")
+        assert torch.isfinite(feat.t).all()
+    # one float short must be refused, not overrun
+    rc = lib.dgvit_got_forward(ctypes.byref(cfg), table, _p(img), _p(goal), _p(feat.t), _p(ws.t), nws - 1, B, 1, 0.9, 1234, None, _st())
+    assert rc == -4
+    nsc = lib.dgvit_got_backward_scratch_floats(ctypes.byref(cfg), B)
+    sc, dgoal = Guarded(nsc), Guarded(B * dim)
+    gr = [Guarded(p.numel()) for p in params]
+    gtable = (ctypes.c_void_p * len(params))(*[g.t.data_ptr() for g in gr])
+    dfeat = torch.randn(B, dim, device="cuda")
+    rc = lib.dgvit_got_backward(ctypes.byref(cfg), table, gtable, _p(dfeat), _p(dgoal.t), _p(ws.t), nws, _p(sc.t), nsc, B, 0.9, 1234, None, _st())
+    _lib.check(rc, "dgvit_got_backward")
+    torch.cuda.synchronize()
+    sc.check("backward scratch"); dgoal.check("dgoal"); ws.check("workspace during backward")
+    for i, g in enumerate(gr):
+        g.check(f"gradient {i}")
+        assert torch.isfinite(g.t).all(), f"gradient {i} has non-finite entries (partly unwritten?)"
+    # the raw call did the real thing: in eval mode (keep = 1) it reproduces the product module bit for bit
+    nws0 = lib.dgvit_got_workspace_floats(ctypes.byref(cfg), B, 0)
+    ws0, feat0 = Guarded(nws0), Guarded(B * dim)
+    _lib.check(lib.dgvit_got_forward(ctypes.byref(cfg), table, _p(img), _p(goal), _p(feat0.t), _p(ws0.t), nws0, B, 0, 1.0, 0, None, _st()),
+               "dgvit_got_forward")
+    with torch.no_grad():
+        assert torch.equal(m.eval()(img, goal).reshape(-1), feat0.t)
+
+
+@pytest.mark.parametrize("shape", [((48, 48), (12, 12), 64, 2, 2, 64, 256, 3), ((80, 112), (16, 16), 72, 1, 3, 64, 200, 2)])
+def test_canaries_encoder_bf16(amd, shape):
+    from dgvit_amd import _lib
+    lib = _lib.load()
+    image, patch, dim, depth, heads, dh, mlp, B = shape
+    torch.manual_seed(0)
+    m = amd.GoT(image_size=image, patch_size=patch, num_classes=2, dim=dim, depth=depth, heads=heads, mlp_dim=mlp, channels=1).cuda()
+    cfg = _lib.dgvit_config(*m._cfg)
+    params = [p.detach().contiguous() for p in m.param_table()]
+    table = (ctypes.c_void_p * len(params))(*[p.data_ptr() for p in params])
+    img, goal = torch.rand(B, *image, device="cuda"), torch.randn(B, dim, device="cuda")
+    nwp = lib.dgvit_got_bf16_weight_elems(ctypes.byref(cfg))
+    wp = Guarded(nwp, torch.bfloat16)
+    _lib.check(lib.dgvit_got_pack_weights_bf16(ctypes.byref(cfg), table, _p(wp.t), nwp, 1, _st()), "pack")
+    torch.cuda.synchronize()
+    wp.check("bf16 weight arena")
+    for save in (0, 1):
+        nws = lib.dgvit_got_bf16_workspace_bytes(ctypes.byref(cfg), B, save)
+        ws, feat = Guarded(nws, torch.uint8), Guarded(B * dim)
+        rc = lib.dgvit_got_forward_bf16(ctypes.byref(cfg), table, _p(wp.t), _p(img), _p(goal), _p(feat.t), _p(ws.t), nws, B, save, 0.9, 77,
+                                        None, _st())
+        _lib.check(rc, "dgvit_got_forward_bf16")
+        torch.cuda.synchronize()
+        ws.check(f"bf16 workspace (save={save})"); feat.check("feat"); wp.check("weight arena during forward")
+        assert torch.isfinite(feat.t).all()
+    nsc = lib.dgvit_got_bf16_backward_scratch_bytes(ctypes.byref(cfg), B)
+    sc, dgoal = Guarded(nsc, torch.uint8), Guarded(B * dim)
+    gr = [Guarded(p.numel()) for p in params]
+    gtable = (ctypes.c_void_p * len(params))(*[g.t.data_ptr() for g in gr])
+    dfeat = torch.randn(B, dim, device="cuda")
+    rc = lib.dgvit_got_backward_bf16(ctypes.byref(cfg), table, _p(wp.t), gtable, _p(dfeat), _p(dgoal.t), _p(img), _p(ws.t), nws, _p(sc.t), nsc, B,
+                                     0.9, 77, None, _st())
+    _lib.check(rc, "dgvit_got_backward_bf16")
+    torch.cuda.synchronize()
+    sc.check("bf16 backward scratch"); dgoal.check("dgoal"); ws.check("bf16 workspace during backward")
+    for i, g in enumerate(gr):
+        g.check(f"gradient {i}")
+        assert torch.isfinite(g.t).all()
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 128, 160), (2, 84, 84), (5, 29, 33)])
+def test_canaries_cnn_stack(amd, B, H, W):
+    from dgvit_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(0)
+    shapes = [(16, 1, 5, 5), (16,), (64, 16, 5, 5), (64,), (256, 64, 5, 5), (256,)]
+    params = [torch.randn(*s, device="cuda") * 0.1 for s in shapes]
+    table = (ctypes.c_void_p * 6)(*[p.data_ptr() for p in params])
+    img = torch.rand(B, H, W, device="cuda")
+    nws, nsc = lib.dgvit_cnn_workspace_floats(B, H, W), lib.dgvit_cnn_forward_scratch_floats(B, H, W)
+    ws, sc, feat = Guarded(nws), Guarded(nsc), Guarded(B * 256)
+    _lib.check(lib.dgvit_cnn_forward(_p(img), table, _p(feat.t), _p(ws.t), nws, _p(sc.t), nsc, B, H, W, _st()), "dgvit_cnn_forward")
+    torch.cuda.synchronize()
+    ws.check("cnn workspace"); sc.check("cnn forward scratch"); feat.check("cnn feat")
+    nsb = lib.dgvit_cnn_backward_scratch_floats(B, H, W)
+    sb = Guarded(nsb)
+    gr = [Guarded(p.numel()) for p in params]
+    gtable = (ctypes.c_void_p * 6)(*[g.t.data_ptr() for g in gr])
+    dfeat = torch.randn(B, 256, device="cuda")
+    _lib.check(lib.dgvit_cnn_backward(_p(img), table, gtable, _p(dfeat), _p(ws.t), nws, _p(sb.t), nsb, B, H, W, _st()), "dgvit_cnn_backward")
+    torch.cuda.synchronize()
+    sb.check("cnn backward scratch"); ws.check("cnn workspace during backward")
+    for i, g in enumerate(gr):
+        g.check(f"cnn gradient {i}")
+        assert torch.isfinite(g.t).all()
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1, 2, 128, 0), (33, 130, 66, 1), (512, 128, 258, 1), (7, 32, 3, 0), (2050, 2, 128, 0)])
+def test_canaries_linear(amd, M, N, K, act):
+    from dgvit_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(0)
+    x, w, b = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda"), torch.randn(N, device="cuda")
+    y = Guarded(M * N)
+    _lib.check(lib.dgvit_linear_forward(_p(x), _p(w), _p(b), _p(y.t), M, N, K, act, _st()), "dgvit_linear_forward")
+    torch.cuda.synchronize()
+    y.check("linear y")
+    ref = torch.nn.functional.linear(x.double().cpu(), w.double().cpu(), b.double().cpu())
+    ref = ref.clamp_min(0) if act else ref
+    np.testing.assert_allclose(y.t.view(M, N).cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    nsc = lib.dgvit_linear_backward_scratch_floats(M, N, K)
+    sc, dx, dw, db = Guarded(nsc), Guarded(M * K), Guarded(N * K), Guarded(N)
+    dy = torch.randn(M, N, device="cuda")
+    _lib.check(lib.dgvit_linear_backward(_p(dy), _p(x), _p(w), _p(y.t), _p(dx.t), _p(dw.t), _p(db.t), _p(sc.t), nsc, M, N, K, act, _st()),
+               "dgvit_linear_backward")
+    torch.cuda.synchronize()
+    for g, what in ((sc, "scratch"), (dx, "dx"), (dw, "dw"), (db, "db")):
+        g.check(f"linear backward {what}")
+    assert torch.isfinite(dx.t).all() and torch.isfinite(dw.t).all() and torch.isfinite(db.t).all()
+
+
+# ------------------------------------------------------------------------------------------------ RCCL on one rank
+def test_gradsync_collective_branch_on_a_one_rank_rccl_group(amd):
+    """backend "nccl" is RCCL on ROCm.  A one-rank group makes all_reduce the identity, so the collective branch of
+    GradSync.sync() (buckets over the fused backward's flat gradient buffer, then /world) can run on this one-GPU box:
+    gradients must come back unchanged, and FlatAdam must still pick the buffer up in place."""
+    import torch.distributed as dist
+    from dgvit_amd.parallel import GradSync
+    from dgvit_amd.optim import FlatAdam, home_of
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29000 + os.getpid() % 2000)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        cfg = O.GoTConfig(image=(84, 84), patch=(12, 12), dim=64, depth=2, heads=2)
+        kw = dict(image_size=cfg.image, patch_size=cfg.patch)
+        m = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, **kw), O.make_params(O.policy_param_spec(cfg), 9)).eval().to("cuda")
+        img, pstate, _, _ = (t.cuda() for t in O.make_inputs(cfg, 8, 9))
+        opt = FlatAdam([m], lr=1e-3)
+        sync = GradSync([m], force_collective=True, bucket_bytes=64 << 10)      # small buckets: several collectives per buffer
+        before = {k: p.detach().clone() for k, p in m.named_parameters()}
+        sync.broadcast_parameters(0)
+        for k, p in m.named_parameters():
+            assert torch.equal(p, before[k]), k
+        sync.zero_grad()
+        mean, log_std = m([img, pstate])
+        ((mean ** 2).mean() + (log_std ** 2).mean()).backward()
+        ref = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+        sync.sync()
+        torch.cuda.synchronize()
+        assert sync.grad_numel() == sum(g.numel() for g in ref.values())
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                assert torch.equal(p.grad, ref[k]), f"{k}: gradient changed by a one-rank all-reduce"
+        opt.step()
+        assert home_of(m).zero_copy_elems > 0
+        torch.cuda.synchronize()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ frozen parameters, re-entry
+@pytest.mark.parametrize("bf16", [False, True])
+def test_frozen_encoder_skips_weight_gradients(amd, bf16):
+    """The reference's heads-only optimiser (DRL.py:145-148) with the encoder frozen (requires_grad off): encoder gradients are
+    None, head gradients and the gradient w.r.t. the goal embedding equal the unfrozen run's, and the C ABI is handed NULL
+    gradient slots (no weight-gradient GEMMs)."""
+    cfg = O.GoTConfig(image=(48, 48), patch=(12, 12), dim=64, depth=2, heads=2)
+    kw = dict(image_size=cfg.image, patch_size=cfg.patch)
+    a = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, **kw), O.make_params(O.policy_param_spec(cfg), 4)).eval().to("cuda")
+    b = copy.deepcopy(a)
+    if bf16:
+        a.trans.set_compute_dtype(torch.bfloat16); b.trans.set_compute_dtype(torch.bfloat16)
+    for p in b.trans.parameters():
+        p.requires_grad_(False)
+    img, pstate, _, _ = (t.cuda() for t in O.make_inputs(cfg, 6, 4))
+    for m in (a, b):
+        mean, log_std = m([img, pstate])
+        ((mean ** 2).mean() + (log_std ** 2).mean()).backward()
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if k.startswith("trans."):
+            assert pb.grad is None, k
+        elif pa.grad is not None:
+            assert torch.equal(pa.grad, pb.grad), k      # same kernels on the same data: bit identical
+    assert b.fc_embed.weight.grad is not None
+    # a partly frozen encoder: only the LayerNorm parameters train
+    c = copy.deepcopy(a)
+    for k, p in c.trans.named_parameters():
+        p.requires_grad_(".norm." in k)
+    mean, log_std = c([img, pstate])
+    ((mean ** 2).mean() + (log_std ** 2).mean()).backward()
+    for (k, pa), (_, pc) in zip(a.named_parameters(), c.named_parameters()):
+        if k.startswith("trans.") and ".norm." not in k:
+            assert pc.grad is None, k
+        elif pa.grad is not None:
+            assert torch.equal(pa.grad, pc.grad), k
+
+
+def test_second_backward_raises_a_clear_error(amd):
+    m = _small_got(amd).eval()
+    img, goal = torch.rand(2, 48, 48, device="cuda"), torch.randn(2, 64, device="cuda", requires_grad=True)
+    f = m(img, goal).sum()
+    f.backward(retain_graph=True)
+    with pytest.raises(amd.DgvitError, match="second time"):
+        f.backward()
+
+
+# ------------------------------------------------------------------------------------------------ optimiser host logic
+def test_flat_adam_and_soft_update_share_one_home(amd):
+    """bench.py's pattern: flatten_parameters(critic), FlatAdam([critic]), soft_update(target, critic).  Round 1 re-homed the
+    parameters twice and silently fell back to a Python loop; now there is one flat buffer and one Polyak kernel."""
+    from dgvit_amd.optim import FlatAdam, flatten_parameters, soft_update, home_of
+    torch.manual_seed(0)
+    crt = amd.GoTQNetwork(2, 2, 1, 2, 64, image_size=(48, 48), patch_size=(12, 12)).to("cuda").eval()   # eval: no dropout draw
+    tgt = copy.deepcopy(crt)
+    ref_c, ref_t = copy.deepcopy(crt), copy.deepcopy(crt)
+    flat = flatten_parameters(crt)
+    flatten_parameters(tgt)
+    opt = FlatAdam([crt], lr=1e-3)
+    assert home_of(crt).flat.data_ptr() == flat.data_ptr() and home_of(crt).intact() and home_of(tgt).intact()
+    ropt = torch.optim.Adam(ref_c.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(0)
+    img, ps, act = torch.rand(4, 48, 48, generator=g).cuda(), torch.rand(4, 2, generator=g).cuda(), torch.rand(4, 2, generator=g).cuda()
+    for _ in range(2):
+        for net, o in ((crt, opt), (ref_c, ropt)):
+            o.zero_grad()
+            q1, q2 = net([img, ps, act])
+            ((q1 ** 2).mean() + (q2 ** 2).mean()).backward()
+            o.step()
+        soft_update(tgt, crt, 0.05)
+        for tp, sp in zip(ref_t.parameters(), ref_c.parameters()):
+            tp.data.copy_(tp.data * 0.95 + sp.data * 0.05)
+    assert home_of(crt).intact() and home_of(tgt).intact()
+    for (k, a), (_, b) in zip(tgt.named_parameters(), ref_t.named_parameters()):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+    assert bool(torch.isfinite(home_of(crt).exp_avg).all()) and bool(torch.isfinite(home_of(crt).exp_avg_sq).all())
+
+
+def test_flat_adam_parameter_subsets_and_late_gradients(amd):
+    """torch.optim.Adam semantics the reference relies on: an optimiser over a sub-set of a network's parameters
+    (DRL.py:145-148), parameters without a gradient are skipped, a parameter that first gets a gradient at a later step
+    starts its own bias correction then."""
+    from dgvit_amd.optim import FlatAdam
+    cfg = O.GoTConfig(image=(48, 48), patch=(12, 12), dim=64, depth=1, heads=2)
+    kw = dict(image_size=cfg.image, patch_size=cfg.patch)
+    a = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, **kw), O.make_params(O.policy_param_spec(cfg), 8)).eval().to("cuda")
+    b = copy.deepcopy(a)
+
+    def subset(m):
+        return list(m.fc1.parameters()) + list(m.fc2.parameters()) + list(m.mean_linear.parameters()) + list(m.log_std_linear.parameters())
+    oa, ob = FlatAdam(subset(a), lr=3e-3), torch.optim.Adam(subset(b), lr=3e-3)
+    img, pstate, _, _ = (t.cuda() for t in O.make_inputs(cfg, 4, 8))
+    for it in range(4):
+        for m, o in ((a, oa), (b, ob)):
+            for p in m.parameters():
+                p.grad = None
+            mean, log_std = m([img, pstate])
+            # steps 0-1: the loss ignores log_std (its Linear gets no gradient); it joins from step 2 on
+            loss = (mean ** 2).mean() if it < 2 else (mean ** 2).mean() + ((log_std + 1) ** 2).mean()
+            loss.backward()
+            o.step()
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+    sd = oa.state_dict()
+    steps = [None if s is None else s["step"] for s in sd["state"]]
+    assert steps == [4, 4, 4, 4, 4, 4, 2, 2]
+    oa2 = FlatAdam(subset(a), lr=3e-3)
+    oa2.load_state_dict(sd)
+    assert [None if s is None else s["step"] for s in oa2.state_dict()["state"]] == steps
