@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-c5", action="store_true", help="skip the secondary config-5 (224x224 ViT-Base, bf16) forward measurement")
     ap.add_argument("--wgrad-overlap", action="store_true", help="A/B: weight-gradient GEMMs on the helper stream (+5%% frames/s, blurs per-kernel timing)")
     ap.add_argument("--dense-last-block", action="store_true", help="A/B: compute the last block for every token")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="rehearsal of the N > 1 path on one GPU: initialise the RCCL process group even for one rank and run the "
+                         "gradient all-reduce (a one-rank all-reduce is the identity) inside every step")
     return ap.parse_args()
 
 
@@ -207,12 +210,15 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("DGVIT_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse several ranks on one card
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev)   # RCCL
         else:
             dist.init_process_group(backend)
 
@@ -227,7 +233,7 @@ def main():
     B = args.batch
     torch.manual_seed(3407)                      # identical initial weights on every rank (config.yaml:7 SEED)
     model = dgvit_amd.GoTPolicy(2, 2, DEPTH, HEADS, DIM, image_size=IMAGE, patch_size=PATCH).to(dev).train()
-    sync = GradSync([model])
+    sync = GradSync([model], force_collective=args.force_collective)
     sync.broadcast_parameters(0)
     from dgvit_amd.optim import FlatAdam
     opt = FlatAdam([model], lr=1e-4)            # torch.optim.Adam semantics, one HIP kernel per flat block
@@ -239,14 +245,14 @@ def main():
     def step():
         sync.zero_grad()
         mean, log_std = model([img, pstate])
-        loss = ((mean - tgt_mean) ** 2).mean() + ((log_std - tgt_ls) ** 2).mean()
+        loss = torch.nn.functional.mse_loss(mean, tgt_mean) + torch.nn.functional.mse_loss(log_std, tgt_ls)
         loss.backward()
         sync.sync()
         opt.step()
         return loss
 
     def fence():
-        if world > 1:
+        if world > 1 or args.force_collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -297,8 +303,11 @@ def main():
             dtf = (time.perf_counter() - t0) / args.steps
         model.train()
         ffl = _syn.fwd_flops_per_frame(IMAGE, PATCH, DIM, DEPTH, HEADS)
+        ffx = _syn.fwd_flops_per_frame_executed(IMAGE, PATCH, DIM, DEPTH, HEADS, prune_last=not args.dense_last_block)
         forward_only = {"frames_per_s": round(B / dtf, 1), "ms_per_pass": round(dtf * 1e3, 3), "tflops_dense": round(B / dtf * ffl / 1e12, 2),
                         "frac_of_f32_mfma_peak": round(B / dtf * ffl / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                        "tflops_executed": round(B / dtf * ffx / 1e12, 2),
+                        "frac_of_f32_mfma_peak_executed": round(B / dtf * ffx / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                         "note": "GoTPolicy forward (eval, no_grad), B=512 84x84; dense FLOPs of SURVEY 8(d); target of the north star: >= 0.5"}
 
     # A/B outside the timed region (N = 1 only): the same step with each layer's weight-gradient GEMMs on the library's helper
@@ -322,6 +331,7 @@ def main():
         frames = B * world * args.steps
         fps = frames / dt
         fwd = synthetic.fwd_flops_per_frame(IMAGE, PATCH, DIM, DEPTH, HEADS)
+        fwd_exec = synthetic.fwd_flops_per_frame_executed(IMAGE, PATCH, DIM, DEPTH, HEADS, prune_last=not args.dense_last_block)
         gemm_tflops = (work[0] / 1e12) / (ms[0] / 1e3) if ms[0] > 0 else 0.0
 
         def per_step(k):   # sampled average launch duration x launches of that kind per step
@@ -354,6 +364,10 @@ def main():
                          "launches_timed": int(cnt[0]), "launches_in_region": int(cnt_all[0]),
                          "timing": f"HIP events around every {args.profile_stride}-th launch of the kernel inside the timed region"},
             "end_to_end": {"tflops": round(fps * 3 * fwd / 1e12, 2), "frac_of_peak": round(fps * 3 * fwd / 1e12 / world / PEAK_F32_MFMA_TFLOPS, 4),
+                           "tflops_executed": round(fps * 3 * fwd_exec / 1e12, 2),
+                           "frac_of_peak_executed": round(fps * 3 * fwd_exec / 1e12 / world / PEAK_F32_MFMA_TFLOPS, 4),
+                           "flops_note": "tflops credits the DENSE model FLOPs of SURVEY 8(d) (the token-0-only last block skips 13.7 % of them); "
+                                         "tflops_executed counts only the FLOPs the schedule runs",
                            "gemm_ms_per_step": round(per_step(0), 3), "attn_fwd_ms_per_step": round(per_step(1), 3),
                            "attn_bwd_ms_per_step": round(per_step(2), 3), "final_loss": round(final_loss, 5),
                            "per_step_note": "isolated launch durations (sampled) x launches per step; back-to-back launches overlap "
@@ -370,7 +384,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_collective:
         dist.destroy_process_group()
 
 

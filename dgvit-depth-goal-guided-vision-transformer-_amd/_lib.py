@@ -46,6 +46,8 @@ SIGNATURES = {
     "dgvit_set_gemm_tile": (None, [_I]),
     "dgvit_set_prune_last_layer": (None, [_I]),
     "dgvit_set_wgrad_overlap": (None, [_I]),
+    "dgvit_set_grouped_reduce": (None, [_I]),
+    "dgvit_set_gemm_split": (None, [_I]),
     "dgvit_layernorm_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dgvit_layernorm_backward_scratch_floats": (_LL, [_I, _I]),
     "dgvit_layernorm_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _P]),

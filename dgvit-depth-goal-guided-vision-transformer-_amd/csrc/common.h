@@ -55,7 +55,20 @@ struct GemmParams {
   long long slab_stride; // EPI_SPLITK: floats between consecutive z slabs
   int colsum;            // EPI_SPLITK: also write sum_k A[k][m] at slab[z][M*N + m] (bias gradient)
   int evec;              // set by gemm_f32: epilogue may use float4 global accesses
+  // in-launch split-K of the NT / NN forms (gemm_split_plan): tiles >= split_from are cut into nsplit k-slices of kchunk_split;
+  // `counters` (one int per tile, zero on entry, left zero) and `slabs` (gemm_split_plan().slab_floats) come from the caller;
+  // counters == nullptr disables splitting
+  int* counters; float* slabs;
+  long long slab_capacity; int counter_capacity;   // floats / ints available behind `slabs` / `counters`
+  int split_from, nsplit, kchunk_split;            // filled in at launch
 };
+
+struct GemmSplitPlan {
+  int tiles, split_from, nsplit, kchunk;   // nsplit <= 1: no split
+  long long slab_floats;                   // scratch the launch needs
+};
+// the split decision for C (M x N) = A B over K with the tile the automatic choice picks; used for sizing and at launch
+GemmSplitPlan gemm_split_plan(int layout, int M, int N, int K);
 
 // live timing hooks (profile.hip); slot < 0 = not recording
 int profile_begin(int kind, double work, hipStream_t st);
@@ -63,6 +76,23 @@ void profile_end(int slot, hipStream_t st);
 enum { PROF_GEMM = 0, PROF_ATTN_FWD = 1, PROF_ATTN_BWD = 2, PROF_OTHER = 3 };
 
 int gemm_f32(int layout, int epi, const GemmParams& p, int nsplit, hipStream_t stream);
+
+// Deterministic fixed-order reductions of split-K slabs / per-workgroup column partials, several of them per launch.
+#define DGVIT_REDUCE_JOBS 8
+struct ReduceJob {
+  const float* slabs; float* out1; float* out2;
+  long long n4, n14, stride4;   // float4 columns in all / going to out1; float4s between consecutive slabs
+  int nslab, cw_log;            // slabs to sum; log2 of the float4 columns per 256-thread block (6 or 4)
+};
+struct ReduceGroup {
+  ReduceJob job[DGVIT_REDUCE_JOBS];
+  int first_block[DGVIT_REDUCE_JOBS + 1];
+  int njobs;
+};
+void reduce_group_init(ReduceGroup& g);
+int reduce_group_add(ReduceGroup& g, const float* slabs, float* out1, long long n1, float* out2, long long n, int nslab,
+                     long long slab_stride, hipStream_t stream);
+int reduce_group_flush(ReduceGroup& g, hipStream_t stream);
 int reduce_slabs(const float* slabs, float* out, long long n, int nslab, long long slab_stride, hipStream_t stream);
 int reduce_slabs2(const float* slabs, float* out1, long long n1, float* out2, long long n, int nslab, long long slab_stride,
                   hipStream_t stream);

@@ -11,6 +11,7 @@
 
 static int g_prune_last = 1;  // last block: only token 0 feeds the output (GoalFormer.py:167)
 static int g_overlap_wgrad = 0;  // opt-in: run weight-gradient GEMMs on a helper stream beside the data-gradient chain
+static int g_group_reduce = 1;   // one grouped slab / partial reduction per layer (0: one launch per weight gradient, A/B knob)
 
 // ---------------------------------------------------------------------------------------------- helper stream
 // dgvit_got_backward forks every weight-gradient GEMM (+ its slab reduction) onto one internal non-blocking
@@ -99,8 +100,9 @@ long long wgrad_scratch(int M, int N, int K) { return (long long)wgrad_splits(M,
 
 // dW (M x N) = A^T B with A (K x M, lda), B (K x N, ldb); optional db (M) = column sums of A (fused in the kernel);
 // dW == nullptr: the weight is frozen (its requires_grad is off): only the bias gradient, if wanted, is computed.
+// grp != null: the slab reduction is queued there and `scratch` must stay untouched until the caller has flushed the group.
 int wgrad(const float* A, int lda, const float* B, int ldb, float* dW, float* db, int M, int N, int K, float* scratch,
-          long long scratch_floats, hipStream_t st) {
+          long long scratch_floats, hipStream_t st, ReduceGroup* grp = nullptr) {
   if (!dW) {
     if (!db) return DGVIT_OK;
     if (scratch_floats < (long long)colsum_blocks(K) * M) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "wgrad: scratch too small for the bias gradient");
@@ -117,15 +119,41 @@ int wgrad(const float* A, int lda, const float* B, int ldb, float* dW, float* db
   const int ns_eff = (K + p.kchunk - 1) / p.kchunk;
   TRY(gemm_f32(GEMM_TN, EPI_SPLITK, p, ns_eff, st));
   const long long mn = (long long)M * N;
-  if (db && mn % 4 == 0) return reduce_slabs2(scratch, dW, mn, db, mn + M, ns_eff, slab, st);
-  TRY(reduce_slabs(scratch, dW, mn, ns_eff, slab, st));
-  if (db) return reduce_slabs(scratch + mn, db, M, ns_eff, slab, st);
-  return DGVIT_OK;
+  ReduceGroup local;
+  if (!grp) reduce_group_init(local);
+  ReduceGroup& g = grp ? *grp : local;
+  if (db && mn % 4 == 0) {
+    TRY(reduce_group_add(g, scratch, dW, mn, db, mn + M, ns_eff, slab, st));
+  } else {
+    TRY(reduce_group_add(g, scratch, dW, mn, nullptr, mn, ns_eff, slab, st));
+    if (db) TRY(reduce_group_add(g, scratch + mn, db, M, nullptr, M, ns_eff, slab, st));
+  }
+  return grp ? DGVIT_OK : reduce_group_flush(local, st);
 }
 
 struct Dims {
   int B, P, N, D, I, M, L, H, dh, pd, pool_mean;
   long long T;
+};
+
+// scratch of the in-launch split-K GEMMs (gemm.hip): fp32 partial tiles + one arrival counter per output tile
+struct SplitNeed {
+  long long slab = 0;
+  long long tiles = 0;
+  void add(int layout, long long M, int N, int K) {
+    if (M <= 0) return;
+    const GemmSplitPlan pl = gemm_split_plan(layout, (int)M, N, K);
+    if (pl.nsplit > 1) {
+      slab = std::max(slab, pl.slab_floats);
+      tiles = std::max<long long>(tiles, pl.tiles);
+    }
+  }
+};
+struct SplitBuf {
+  int* counters = nullptr; float* slabs = nullptr; long long slab_cap = 0; int ncounters = 0;
+  void attach(GemmParams& p) const {
+    p.counters = counters; p.slabs = slabs; p.slab_capacity = slab_cap; p.counter_capacity = ncounters;
+  }
 };
 
 int make_dims(const dgvit_config* c, int batch, Dims& d) {
@@ -149,9 +177,30 @@ int make_dims(const dgvit_config* c, int batch, Dims& d) {
   return DGVIT_OK;
 }
 
+SplitNeed forward_split_need(const Dims& d) {
+  SplitNeed n;
+  const int T = (int)d.T;
+  n.add(GEMM_NT, (long long)d.B * d.P, d.D, d.pd);
+  n.add(GEMM_NT, T, 3 * d.I, d.D); n.add(GEMM_NT, T, 2 * d.I, d.D); n.add(GEMM_NT, d.B, d.I, d.D);
+  for (int tok : {T, d.B}) {
+    n.add(GEMM_NT, tok, d.D, d.I); n.add(GEMM_NT, tok, d.M, d.D); n.add(GEMM_NT, tok, d.D, d.M);
+  }
+  return n;
+}
+SplitNeed backward_split_need(const Dims& d) {
+  SplitNeed n;
+  const int T = (int)d.T;
+  for (int tok : {T, d.B}) {
+    n.add(GEMM_NN, tok, d.M, d.D); n.add(GEMM_NN, tok, d.D, d.M); n.add(GEMM_NN, tok, d.I, d.D); n.add(GEMM_NN, tok, d.D, d.I);
+  }
+  n.add(GEMM_NN, T, d.D, 3 * d.I); n.add(GEMM_NN, T, d.D, 2 * d.I);
+  return n;
+}
+
 // activation workspace carve-up (floats); `save` keeps per-layer buffers distinct
 struct Ws {
   long long patches, x0, pooled, layer0, layer_stride, layer_floats, total;
+  long long sk_counters, sk_slabs, sk_ncounters, sk_slab_floats;   // in-launch split-K scratch (0 floats when no GEMM splits)
   // per-layer offsets relative to the layer base
   long long mean1, rstd1, ln1, qkv, ao, lse, xmid, mean2, rstd2, ln2, h1, a1, xout;
 };
@@ -162,6 +211,10 @@ Ws make_ws(const Dims& d, int save) {
   w.patches = o; o += al4((long long)d.B * d.P * d.pd);
   w.x0 = o; o += al4(d.T * d.D);
   w.pooled = o; o += al4((long long)d.B * d.D);   // token mean (pool='mean' only)
+  const SplitNeed sn = forward_split_need(d);
+  w.sk_ncounters = sn.tiles; w.sk_slab_floats = sn.slab;
+  w.sk_counters = o; o += al4(sn.tiles);
+  w.sk_slabs = o; o += al4(sn.slab);
   long long l = 0;
   w.mean1 = l; l += al4(d.T);
   w.rstd1 = l; l += al4(d.T);
@@ -205,6 +258,8 @@ extern "C" int dgvit_device_count(void) {
 extern "C" void dgvit_set_gemm_tile(int tile) { g_gemm_tile_hint = tile; }
 extern "C" void dgvit_set_prune_last_layer(int on) { g_prune_last = on ? 1 : 0; }
 extern "C" void dgvit_set_wgrad_overlap(int on) { g_overlap_wgrad = on ? 1 : 0; }
+extern "C" void dgvit_set_grouped_reduce(int on) { g_group_reduce = on ? 1 : 0; }
+extern "C" void dgvit_set_gemm_split(int on) { g_gemm_split = on ? 1 : 0; }
 
 // ---------------------------------------------------------------------------------------------- encoder
 extern "C" long long dgvit_got_workspace_floats(const dgvit_config* cfg, int batch, int save) {
@@ -215,7 +270,9 @@ extern "C" long long dgvit_got_workspace_floats(const dgvit_config* cfg, int bat
 
 namespace {
 struct Bs {  // backward scratch carve-up
-  long long dxa, dxb, dln, dqkv, dao, dh1, part, slabs, total, slabs_floats;
+  long long dxa, dxb, dln, dqkv, dao, dh1, part, part_ln2, part_ln1, slabs, total, slabs_floats;
+  long long sl_fc2, sl_fc1, sl_out, sl_qkv, n_fc2, n_fc1, n_out, n_qkv;   // a layer's four weight gradients keep separate slab regions
+  long long sk_counters, sk_slabs, sk_ncounters, sk_slab_floats;          // in-launch split-K scratch of the data-gradient GEMMs
 };
 Bs make_bs(const Dims& d) {
   Bs s;
@@ -236,13 +293,23 @@ Bs make_bs(const Dims& d) {
   const long long rp = (long long)rmsnorm_bwd_blocks(d.B) * d.D;
   if (rp > part) part = rp;
   s.part = o; o += al4(part);
-  long long sl = wgrad_scratch(3 * d.I, d.D, (int)d.T);
-  long long t;
-  if ((t = wgrad_scratch(d.D, d.I, (int)d.T)) > sl) sl = t;
-  if ((t = wgrad_scratch(d.M, d.D, (int)d.T)) > sl) sl = t;
-  if ((t = wgrad_scratch(d.D, d.M, (int)d.T)) > sl) sl = t;
-  if ((t = wgrad_scratch(d.D, d.pd, d.B * d.P)) > sl) sl = t;
+  // the two LayerNorm backward passes of a layer keep their dgamma / dbeta partials until the layer's ONE grouped reduction
+  const long long lnp = al4((long long)layernorm_bwd_blocks((int)d.T) * 2 * d.D);
+  s.part_ln2 = o; o += lnp;
+  s.part_ln1 = o; o += lnp;
+  // ... and so do its four split-K weight gradients (the last block's to_qkv gradient is two GEMMs: Q rows, K/V rows)
+  s.n_fc2 = wgrad_scratch(d.D, d.M, (int)d.T);
+  s.n_fc1 = wgrad_scratch(d.M, d.D, (int)d.T);
+  s.n_out = wgrad_scratch(d.D, d.I, (int)d.T);
+  s.n_qkv = std::max(wgrad_scratch(3 * d.I, d.D, (int)d.T), wgrad_scratch(d.I, d.D, d.B) + wgrad_scratch(2 * d.I, d.D, (int)d.T));
+  s.sl_fc2 = 0; s.sl_fc1 = s.n_fc2; s.sl_out = s.sl_fc1 + s.n_fc1; s.sl_qkv = s.sl_out + s.n_out;
+  long long sl = s.sl_qkv + s.n_qkv;
+  sl = std::max(sl, wgrad_scratch(d.D, d.pd, d.B * d.P));
   s.slabs = o; s.slabs_floats = sl; o += sl;
+  const SplitNeed sn = backward_split_need(d);
+  s.sk_ncounters = sn.tiles; s.sk_slab_floats = sn.slab;
+  s.sk_counters = o; o += al4(sn.tiles);
+  s.sk_slabs = o; o += al4(sn.slab);
   s.total = o;
   return s;
 }
@@ -270,6 +337,12 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
   for (int i = 0; i < P_L0 + DGVIT_PARAMS_PER_LAYER * d.L; ++i) DGVIT_CHECK_ARG(params[i], "parameter %d is null", i);
   const int T = (int)d.T;
 
+  SplitBuf sk;
+  if (w.sk_slab_floats > 0) {
+    sk.counters = reinterpret_cast<int*>(ws + w.sk_counters); sk.ncounters = (int)w.sk_ncounters;
+    sk.slabs = ws + w.sk_slabs; sk.slab_cap = w.sk_slab_floats;
+    HIP_TRY(hipMemsetAsync(sk.counters, 0, sizeof(int) * w.sk_ncounters, st));   // every split GEMM leaves them zero again
+  }
   // patch embedding (GoalFormer.py:137-139,157) + goal token, positional embedding, dropout (:160-163)
   float* patches = ws + w.patches;
   float* x = ws + w.x0;
@@ -279,6 +352,7 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     p.bias = params[P_PB];
     p.res = params[P_POS]; p.ldr = d.D; p.res_mod = d.P;  // + pos_embedding[1 + patch]
     p.c_rgrp = d.P;                                       // row (b, patch) -> token row b*N + 1 + patch
+    sk.attach(p);
     TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
   }
   TRY(goal_row(goal, params[P_POS], x, d.B, d.N, d.D, st));
@@ -297,17 +371,21 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     TRY(layernorm_fwd(x, lp[L_LN1W], lp[L_LN1B], lb + w.ln1, lb + w.mean1, lb + w.rstd1, T, d.D, 1e-5f, 1, st));
     if (!last) {
       GemmParams p = gp(lb + w.ln1, d.D, lp[L_QKV], d.D, lb + w.qkv, 3 * d.I, T, 3 * d.I, d.D);
+      sk.attach(p);
       TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
     } else {
       GemmParams kv = gp(lb + w.ln1, d.D, lp[L_QKV] + (long long)d.I * d.D, d.D, lb + w.qkv + d.I, 3 * d.I, T, 2 * d.I, d.D);
+      sk.attach(kv);
       TRY(gemm_f32(GEMM_NT, EPI_STORE, kv, 1, st));
       GemmParams q = gp(lb + w.ln1, rs * d.D, lp[L_QKV], d.D, lb + w.qkv, rs * 3 * d.I, tok, d.I, d.D);
+      sk.attach(q);
       TRY(gemm_f32(GEMM_NT, EPI_STORE, q, 1, st));
     }
     TRY(attention_fwd(lb + w.qkv, lb + w.ao, save ? lb + w.lse : nullptr, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
     {
       GemmParams p = gp(lb + w.ao, rs * d.I, lp[L_OUTW], d.I, lb + w.xmid, rs * d.D, tok, d.D, d.I);
       p.bias = lp[L_OUTB]; p.res = x; p.ldr = rs * d.D;
+      sk.attach(p);
       TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
     }
     // x = ff(LN(x)) + x     (GoalFormer.py:104, 42-50)
@@ -315,11 +393,13 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     {
       GemmParams p = gp(lb + w.ln2, rs * d.D, lp[L_FC1W], d.D, lb + w.h1, d.M, tok, d.M, d.D);   // h1 / a1 are dense (tok, M)
       p.bias = lp[L_FC1B]; p.C2 = lb + w.a1; p.ldc2 = d.M;
+      sk.attach(p);
       TRY(gemm_f32(GEMM_NT, EPI_GELU2, p, 1, st));
     }
     {
       GemmParams p = gp(lb + w.a1, d.M, lp[L_FC2W], d.M, xo, rs * d.D, tok, d.D, d.M);
       p.bias = lp[L_FC2B]; p.res = lb + w.xmid; p.ldr = rs * d.D;
+      sk.attach(p);
       TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
     }
     x = xo;
@@ -357,6 +437,12 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
   float* part = scratch + s.part;
   float* slabs = scratch + s.slabs;
 
+  SplitBuf sk;   // the data-gradient GEMMs all run on the caller's stream, one after the other: one counter / slab region serves them
+  if (s.sk_slab_floats > 0) {
+    sk.counters = reinterpret_cast<int*>(scratch + s.sk_counters); sk.ncounters = (int)s.sk_ncounters;
+    sk.slabs = scratch + s.sk_slabs; sk.slab_cap = s.sk_slab_floats;
+    HIP_TRY(hipMemsetAsync(sk.counters, 0, sizeof(int) * s.sk_ncounters, st));
+  }
   // weight gradients run on the helper stream `sw`; `done[j]` = main must wait for the previous layer's j-th
   // wgrad before overwriting the buffer it reads (dx, dh1, dx2, dqkv)
   hipStream_t sw = st;
@@ -389,49 +475,67 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
     // ---- feed-forward branch: xout = fc2(gelu(fc1(ln2))) + xmid
     // (helper-stream kernels are ordered among themselves, so the slab scratch is reused safely; a `join` before
     //  a main-stream kernel that overwrites a buffer makes sure the wgrads that read it have finished)
+    // (every weight gradient of the layer writes its split-K slabs into a region of its own; their fixed-order sums and the
+    //  two LayerNorm parameter-gradient sums are ONE grouped launch at the end of the layer instead of six)
+    ReduceGroup grp;
+    reduce_group_init(grp);
+    ReduceGroup* gq = g_group_reduce ? &grp : nullptr;   // null: every reduction is launched where it is produced
     TRY(fork());
-    TRY(wgrad(dx, rs * d.D, lb + w.a1, d.M, lg[L_FC2W], lg[L_FC2B], d.D, d.M, tok, slabs, s.slabs_floats, sw));
+    TRY(wgrad(dx, rs * d.D, lb + w.a1, d.M, lg[L_FC2W], lg[L_FC2B], d.D, d.M, tok, slabs + s.sl_fc2, s.n_fc2, sw, gq));
     {
       GemmParams p = gp(dx, rs * d.D, lp[L_FC2W], d.M, dh1, d.M, tok, d.M, d.D);
       p.aux = lb + w.h1; p.ldaux = d.M;
+      sk.attach(p);
       TRY(gemm_f32(GEMM_NN, EPI_DGELU, p, 1, st));  // dh1 = (dx W2) * gelu'(h1)   [previous layer's wgrads joined below]
     }
     TRY(fork());
-    TRY(wgrad(dh1, d.M, lb + w.ln2, rs * d.D, lg[L_FC1W], lg[L_FC1B], d.M, d.D, tok, slabs, s.slabs_floats, sw));
+    TRY(wgrad(dh1, d.M, lb + w.ln2, rs * d.D, lg[L_FC1W], lg[L_FC1B], d.M, d.D, tok, slabs + s.sl_fc1, s.n_fc1, sw, gq));
     {
       GemmParams p = gp(dh1, d.M, lp[L_FC1W], d.D, dln, rs * d.D, tok, d.D, d.M);
+      sk.attach(p);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dln2 = dh1 W1
     }
     if (last) HIP_TRY(hipMemsetAsync(dx2, 0, sizeof(float) * d.T * d.D, st));   // rows other than b*N get no gradient
-    TRY(layernorm_bwd(dln, lb + w.xmid, lb + w.mean2, lb + w.rstd2, lp[L_LN2W], dx, dx2, lg[L_LN2W], lg[L_LN2B], part, tok, d.D, rs, st));
+    TRY(layernorm_bwd(dln, lb + w.xmid, lb + w.mean2, lb + w.rstd2, lp[L_LN2W], dx, dx2, lg[L_LN2W], lg[L_LN2B], scratch + s.part_ln2, tok, d.D,
+                      rs, st, gq));
     // ---- attention branch: xmid = to_out(attn(to_qkv(ln1))) + xin       (dx2 = d xmid)
     TRY(fork());
-    TRY(wgrad(dx2, rs * d.D, lb + w.ao, rs * d.I, lg[L_OUTW], lg[L_OUTB], d.D, d.I, tok, slabs, s.slabs_floats, sw));
+    TRY(wgrad(dx2, rs * d.D, lb + w.ao, rs * d.I, lg[L_OUTW], lg[L_OUTB], d.D, d.I, tok, slabs + s.sl_out, s.n_out, sw, gq));
     {
       GemmParams p = gp(dx2, rs * d.D, lp[L_OUTW], d.I, dao, rs * d.I, tok, d.I, d.D);
+      sk.attach(p);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dao = dxmid Wo
     }
     TRY(attention_bwd(lb + w.qkv, lb + w.ao, dao, lb + w.lse, dqkv, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
     TRY(fork());
     if (!last) {
-      TRY(wgrad(dqkv, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV], nullptr, 3 * d.I, d.D, T, slabs, s.slabs_floats, sw));
+      TRY(wgrad(dqkv, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV], nullptr, 3 * d.I, d.D, T, slabs + s.sl_qkv, s.n_qkv, sw, gq));
       GemmParams p = gp(dqkv, 3 * d.I, lp[L_QKV], d.D, dln, d.D, T, d.D, 3 * d.I);
+      sk.attach(p);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dln1 = dqkv Wqkv
     } else {
       // dWq from the token-0 rows, dWk/dWv from all rows; dln1 = dkv Wkv (+ dq Wq on the token-0 rows)
-      TRY(wgrad(dqkv, rs * 3 * d.I, lb + w.ln1, rs * d.D, lg[L_QKV], nullptr, d.I, d.D, tok, slabs, s.slabs_floats, sw));
-      TRY(wgrad(dqkv + d.I, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV] ? lg[L_QKV] + (long long)d.I * d.D : nullptr, nullptr, 2 * d.I, d.D, T, slabs,
-                s.slabs_floats, sw));
+      const long long nq_slabs = wgrad_scratch(d.I, d.D, tok);
+      TRY(wgrad(dqkv, rs * 3 * d.I, lb + w.ln1, rs * d.D, lg[L_QKV], nullptr, d.I, d.D, tok, slabs + s.sl_qkv, nq_slabs, sw, gq));
+      TRY(wgrad(dqkv + d.I, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV] ? lg[L_QKV] + (long long)d.I * d.D : nullptr, nullptr, 2 * d.I, d.D, T,
+                slabs + s.sl_qkv + nq_slabs, s.n_qkv - nq_slabs, sw, gq));
       GemmParams kv = gp(dqkv + d.I, 3 * d.I, lp[L_QKV] + (long long)d.I * d.D, d.D, dln, d.D, T, d.D, 2 * d.I);
+      sk.attach(kv);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, kv, 1, st));
       GemmParams q = gp(dqkv, rs * 3 * d.I, lp[L_QKV], d.D, dln, rs * d.D, tok, d.D, d.I);
       q.res = dln; q.ldr = rs * d.D;
+      sk.attach(q);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, q, 1, st));
     }
     // dx, dh1, dx2 and dqkv are overwritten from here on (this LayerNorm backward and the next layer): wait for the
     // helper stream.  Only this layer's last wgrad (qkv) can still be running; it overlapped the dln1 GEMM above.
     TRY(join());
-    TRY(layernorm_bwd(dln, xin, lb + w.mean1, lb + w.rstd1, lp[L_LN1W], dx2, dx, lg[L_LN1W], lg[L_LN1B], part, T, d.D, 1, st));
+    TRY(layernorm_bwd(dln, xin, lb + w.mean1, lb + w.rstd1, lp[L_LN1W], dx2, dx, lg[L_LN1W], lg[L_LN1B], scratch + s.part_ln1, T, d.D, 1, st, gq));
+    // the layer's grouped reduction: behind the weight gradients on the helper stream (it also reads this stream's LayerNorm
+    // partials, hence the fork), and the caller's stream waits for it before the slab / partial regions are written again
+    TRY(fork());
+    TRY(reduce_group_flush(grp, sw));
+    TRY(join());
   }
   // ---- token assembly: x0 = dropout(cat(goal, patches W^T + b) + pos)
   if (keep < 1.f) TRY(dropout_inplace(dx, d.T * d.D, seed, seed_dev, keep, st));
@@ -489,7 +593,10 @@ extern "C" int dgvit_linear_backward(const float* dy, const float* x, const floa
 
 // ---------------------------------------------------------------------------------------------- operator exports
 extern "C" long long dgvit_gemm_scratch_floats(int layout, int M, int N, int K) {
-  if (layout != GEMM_TN) return 0;
+  if (layout != GEMM_TN) {   // in-launch split-K: arrival counters (one per tile) + partial tiles; 0 when the shape is not split
+    const GemmSplitPlan pl = gemm_split_plan(layout, M, N, K);
+    return pl.nsplit > 1 ? al4(pl.tiles) + al4(pl.slab_floats) : 0;
+  }
   return wgrad_scratch(M, N, K);
 }
 
@@ -509,6 +616,12 @@ extern "C" int dgvit_gemm(int layout, int epilogue, const float* A, int lda, con
   DGVIT_CHECK_ARG((epilogue != EPI_DGELU && epilogue != EPI_DRELU) || aux, "gemm: epilogue needs aux");
   GemmParams p = gp(A, lda, B, ldb, C, ldc, M, N, K);
   p.bias = bias; p.res = res; p.ldr = ldr; p.C2 = C2; p.ldc2 = ldc2; p.aux = aux; p.ldaux = ldaux;
+  const GemmSplitPlan pl = gemm_split_plan(layout, M, N, K);
+  if (pl.nsplit > 1 && scratch && scratch_floats >= al4(pl.tiles) + al4(pl.slab_floats)) {
+    p.counters = reinterpret_cast<int*>(scratch); p.counter_capacity = pl.tiles;
+    p.slabs = scratch + al4(pl.tiles); p.slab_capacity = scratch_floats - al4(pl.tiles);
+    HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(int) * pl.tiles, st));
+  }
   return gemm_f32(layout, epilogue, p, 1, st);
 }
 

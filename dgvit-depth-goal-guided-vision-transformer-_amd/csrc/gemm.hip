@@ -22,7 +22,17 @@
 // staging LDS so that every global access of the epilogue -- C, residual, GELU input/output -- is a
 // 16-byte-per-lane, 512-byte-per-row coalesced float4; bias / residual / GELU / GELU' / ReLU are applied
 // on the way out.  The weight-gradient form also sums its A tiles over k (= the bias gradient) for free.
+#include <algorithm>
+
 #include "common.h"
+
+#define TRY_RG(expr)      \
+  do {                    \
+    int rc_ = (expr);     \
+    if (rc_) return rc_;  \
+  } while (0)
+
+extern int g_gemm_split;
 
 namespace {
 
@@ -238,11 +248,24 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
   const int wm = wave / T::WVN, wn = wave % T::WVN;
 
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-  const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  // In-launch split-K (forward / data-gradient forms): tiles >= p.split_from are cut into p.nsplit k-slices, one workgroup
+  // each; the slices leave fp32 partial tiles in `p.slabs`, draw a ticket from the tile's counter, and the LAST arriver sums
+  // the slices in slice order (deterministic) and runs the normal epilogue.  Two uses: GEMMs with far fewer tiles than the
+  // chip has workgroup slots (small batches: T = 65 ... 2080 rows, K = 2048), and the last partial round of a large grid
+  // (25600 x 256 outputs = 1600 tiles = 6.25 per CU: the 64 left-over tiles become 256 quarter-tiles).
+  int tile, zs = 0, nz = 1;
+  if (EPI != EPI_SPLITK && p.nsplit > 1 && (int)blockIdx.x >= p.split_from) {
+    const int r = (int)blockIdx.x - p.split_from;
+    tile = p.split_from + r / p.nsplit;
+    zs = r % p.nsplit;
+    nz = p.nsplit;
+  } else {
+    tile = xcd_remap(blockIdx.x, EPI != EPI_SPLITK && p.nsplit > 1 ? p.split_from : tiles_m * tiles_n);
+  }
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  const int kbeg = blockIdx.z * p.kchunk;
-  const int kend = min(p.K, kbeg + p.kchunk);
-  const int nk = (kend - kbeg + BK - 1) / BK;
+  const int kbeg = nz > 1 ? zs * p.kchunk_split : blockIdx.z * p.kchunk;
+  const int kend = min(p.K, kbeg + (nz > 1 ? p.kchunk_split : p.kchunk));
+  const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -378,6 +401,65 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
     for (int e = 0; e < 4; ++e)
       if (n + e < p.N) bias4[e] = p.bias[n + e];
   }
+  // one output row piece (row m, columns n .. n+3, v = the k-complete sums): fused epilogue arithmetic and the global stores
+  auto finish = [&](int m, float (&v)[4]) {
+    float w2[4];
+    long long crow = m;
+    if (EPI == EPI_STORE && p.c_rgrp > 0) crow = (long long)m + m / p.c_rgrp + 1;
+    float* cptr = Cz + crow * p.ldc + n;
+    if (EPI == EPI_STORE) {
+      if (p.res) {
+        const long long rrow = p.res_mod > 0 ? (long long)(m % p.res_mod) + 1 : (long long)m;
+        const float* rp = p.res + rrow * p.ldr + n;
+        if (p.evec) {
+          const float4 q = *reinterpret_cast<const float4*>(rp);
+          v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) v[e] += rp[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+    } else if (EPI == EPI_GELU2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += bias4[e];
+        w2[e] = gelu_erf(v[e]);
+      }
+    } else if (EPI == EPI_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
+    } else if (EPI == EPI_DGELU || EPI == EPI_DRELU) {
+      const float* ap = p.aux + (long long)m * p.ldaux + n;
+      float a4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.evec) {
+        const float4 q = *reinterpret_cast<const float4*>(ap);
+        a4[0] = q.x; a4[1] = q.y; a4[2] = q.z; a4[3] = q.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.N) a4[e] = ap[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = EPI == EPI_DGELU ? v[e] * gelu_erf_grad(a4[e]) : (a4[e] > 0.f ? v[e] : 0.f);
+    }
+    if (p.evec) {
+      *reinterpret_cast<float4*>(cptr) = make_float4(v[0], v[1], v[2], v[3]);
+      if (EPI == EPI_GELU2) *reinterpret_cast<float4*>(p.C2 + (long long)m * p.ldc2 + n) = make_float4(w2[0], w2[1], w2[2], w2[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < p.N) {
+          cptr[e] = v[e];
+          if (EPI == EPI_GELU2) p.C2[(long long)m * p.ldc2 + n + e] = w2[e];
+        }
+    }
+  };
+  // k-slice of a split tile: the raw partial sums go to this slice's dense [BM][BN] slab
+  float* slab = nullptr;
+  if (EPI != EPI_SPLITK && nz > 1) slab = p.slabs + ((long long)(tile - p.split_from) * nz + zs) * (BM * BN);
 #pragma unroll
   for (int ch = 0; ch < NCHUNK; ++ch) {
     if (NCHUNK == 1 || wm == ch) {
@@ -403,105 +485,100 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
         }
     }
     __syncthreads();
-    if (n < p.N) {
+    if (slab) {
+      for (int rr = rr0; rr < CROWS; rr += RPP)
+        *reinterpret_cast<float4*>(slab + (ch * CROWS + rr) * BN + cc) = *reinterpret_cast<const float4*>(smem + rr * CS + cc);
+    } else if (n < p.N) {
       for (int rr = rr0; rr < CROWS; rr += RPP) {
         const int m = m0 + ch * CROWS + rr;
         if (m >= p.M) break;
         const float4 t = *reinterpret_cast<const float4*>(smem + rr * CS + cc);
         float v[4] = {t.x, t.y, t.z, t.w};
-        float w2[4];
-        long long crow = m;
-        if (EPI == EPI_STORE && p.c_rgrp > 0) crow = (long long)m + m / p.c_rgrp + 1;
-        float* cptr = Cz + crow * p.ldc + n;
-        if (EPI == EPI_STORE) {
-          if (p.res) {
-            const long long rrow = p.res_mod > 0 ? (long long)(m % p.res_mod) + 1 : (long long)m;
-            const float* rp = p.res + rrow * p.ldr + n;
-            if (p.evec) {
-              const float4 q = *reinterpret_cast<const float4*>(rp);
-              v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e)
-                if (n + e < p.N) v[e] += rp[e];
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += bias4[e];
-        } else if (EPI == EPI_GELU2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] += bias4[e];
-            w2[e] = gelu_erf(v[e]);
-          }
-        } else if (EPI == EPI_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
-        } else if (EPI == EPI_DGELU || EPI == EPI_DRELU) {
-          const float* ap = p.aux + (long long)m * p.ldaux + n;
-          float a4[4] = {0.f, 0.f, 0.f, 0.f};
-          if (p.evec) {
-            const float4 q = *reinterpret_cast<const float4*>(ap);
-            a4[0] = q.x; a4[1] = q.y; a4[2] = q.z; a4[3] = q.w;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n + e < p.N) a4[e] = ap[e];
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = EPI == EPI_DGELU ? v[e] * gelu_erf_grad(a4[e]) : (a4[e] > 0.f ? v[e] : 0.f);
-        }
-        if (p.evec) {
-          *reinterpret_cast<float4*>(cptr) = make_float4(v[0], v[1], v[2], v[3]);
-          if (EPI == EPI_GELU2) *reinterpret_cast<float4*>(p.C2 + (long long)m * p.ldc2 + n) = make_float4(w2[0], w2[1], w2[2], w2[3]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.N) {
-              cptr[e] = v[e];
-              if (EPI == EPI_GELU2) p.C2[(long long)m * p.ldc2 + n + e] = w2[e];
-            }
-        }
+        finish(m, v);
       }
     }
     if (ch + 1 < NCHUNK) __syncthreads();
   }
+  if (EPI != EPI_SPLITK && nz > 1) {
+    // publish the slab, take a ticket; placement-independent agent-scope release / acquire (cdna_hip_programming.md, Guideline 16)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int ticket = __hip_atomic_fetch_add(p.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = ticket == nz - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+      }
+      *flag = last;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    if (n < p.N) {
+      const float* s0 = p.slabs + (long long)(tile - p.split_from) * nz * (BM * BN);
+      for (int rr = rr0; rr < BM; rr += RPP) {
+        const int m = m0 + rr;
+        if (m >= p.M) break;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < nz; ++z) {   // fixed slice order: bit-reproducible
+          const float4 t = *reinterpret_cast<const float4*>(s0 + (long long)z * (BM * BN) + rr * BN + cc);
+          v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        }
+        finish(m, v);
+      }
+    }
+  }
 }
 
-// out1[0..n1) , out2[0..n-n1)  <-  sum over slabs of slab[z][0..n)
-// 256 threads = 64 float4 columns x 4 slab groups: group y sums slabs y, y+4, y+8, ... (4 loads in flight each),
-// then the four partial sums are combined through LDS in the fixed order ((g0+g1)+(g2+g3)): deterministic.
-__global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out1,
-                                                           float* __restrict__ out2, long long n4, long long n14, int nslab,
-                                                           long long stride) {
-  __shared__ float4 part[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const long long i = (long long)blockIdx.x * 64 + tx;
+// out1[0..n1) , out2[0..n-n1)  <-  sum over slabs of slab[z][0..n), for up to DGVIT_REDUCE_JOBS independent jobs in ONE launch
+// (a transformer layer's four split-K weight gradients + its two LayerNorm parameter-gradient partials).
+// 256 threads = CW float4 columns x GS slab groups (CW * GS = 256; jobs with few columns and many slabs -- LayerNorm partials --
+// take CW = 16, GS = 16): group y sums slabs y, y+GS, y+2GS, ... with 4 loads in flight, then the GS partial sums are combined
+// through LDS in a fixed (tree) order: deterministic for a given (nslab, GS).
+__global__ void __launch_bounds__(256) reduce_group_kernel(const ReduceGroup g) {
+  __shared__ float4 part[256];
+  int j = 0;
+#pragma unroll
+  for (int t = 1; t < DGVIT_REDUCE_JOBS; ++t)
+    if (t < g.njobs && (int)blockIdx.x >= g.first_block[t]) j = t;
+  const ReduceJob job = g.job[j];
+  const int cwl = job.cw_log, CW = 1 << cwl, GS = 256 >> cwl;
+  const int tx = threadIdx.x & (CW - 1), ty = threadIdx.x >> cwl;
+  const long long i = (long long)((int)blockIdx.x - g.first_block[j]) * CW + tx;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (i < n4) {
-    const float4* src = reinterpret_cast<const float4*>(slabs) + i;
-    const long long st4 = stride / 4;
+  if (i < job.n4) {
+    const float4* src = reinterpret_cast<const float4*>(job.slabs) + i;
+    const long long st4 = job.stride4;
     int z = ty;
-    for (; z + 12 < nslab; z += 16) {
-      const float4 a = src[(z + 0) * st4], b = src[(z + 4) * st4], c = src[(z + 8) * st4], d = src[(z + 12) * st4];
+    for (; z + 3 * GS < job.nslab; z += 4 * GS) {
+      const float4 a = src[(z + 0 * GS) * st4], b = src[(z + 1 * GS) * st4], c = src[(z + 2 * GS) * st4], d = src[(z + 3 * GS) * st4];
       s.x += (a.x + b.x) + (c.x + d.x);
       s.y += (a.y + b.y) + (c.y + d.y);
       s.z += (a.z + b.z) + (c.z + d.z);
       s.w += (a.w + b.w) + (c.w + d.w);
     }
-    for (; z < nslab; z += 4) {
+    for (; z < job.nslab; z += GS) {
       const float4 a = src[z * st4];
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
   }
-  part[ty][tx] = s;
+  part[ty * CW + tx] = s;
   __syncthreads();
-  if (ty == 0 && i < n4) {
-    const float4 a = part[0][tx], b = part[1][tx], c = part[2][tx], d = part[3][tx];
-    const float4 r = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
-                                 (a.w + b.w) + (c.w + d.w));
-    if (i < n14) reinterpret_cast<float4*>(out1)[i] = r;
-    else reinterpret_cast<float4*>(out2)[i - n14] = r;
+  for (int half = GS >> 1; half >= 1; half >>= 1) {   // fixed pairing: (y, y + half)
+    if (ty < half) {
+      const float4 a = part[ty * CW + tx], b = part[(ty + half) * CW + tx];
+      part[ty * CW + tx] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    __syncthreads();
+  }
+  if (ty == 0 && i < job.n4) {
+    const float4 r = part[tx];
+    if (i < job.n14) reinterpret_cast<float4*>(job.out1)[i] = r;
+    else reinterpret_cast<float4*>(job.out2)[i - job.n14] = r;
   }
 }
 
@@ -516,8 +593,44 @@ __global__ void __launch_bounds__(256) reduce_slabs_scalar_kernel(const float* _
   else out2[i - n1] = s;
 }
 
+// ---- in-launch split-K policy -------------------------------------------------------------------------------------------
+// (a) few tiles, long K (small batches: T = 65 ... 2080 rows against K = 2048): every tile is cut so that the grid fills the chip;
+// (b) a big grid whose last partial round would leave most CUs idle (tiles mod 256 <= 128: measured at 25600 x 256 x 2048,
+//     1600 tiles = 6.25 per CU run 12 % longer than 1536 tiles): only the left-over tiles are cut, into 256 / r slices.
+// A slice keeps at least 4 k-tiles.  Returns nsplit <= 1 for "do not split".
+inline GemmSplitPlan split_plan(int M, int N, int K, int BM, int BN, int BK, int wg_per_cu) {
+  GemmSplitPlan pl = {};
+  const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  pl.tiles = (int)tiles;
+  pl.nsplit = 1;
+  pl.split_from = (int)tiles;
+  const int KT = (K + BK - 1) / BK, cus = 256, slots = cus * wg_per_cu;
+  if (KT < 8 || tiles <= 0) return pl;
+  int S = 1;
+  long long from = tiles;
+  if (tiles * 2 <= slots) {
+    S = (int)std::min<long long>(KT / 4, slots / tiles);
+    from = 0;
+  } else if (tiles > slots) {
+    const long long r = tiles % cus;
+    if (r > 0 && r <= cus / 2) {
+      S = (int)std::min<long long>(KT / 4, cus / r);
+      from = tiles - r;
+    }
+  }
+  if (S < 2) return pl;
+  const int kt_per = (KT + S - 1) / S;
+  S = (KT + kt_per - 1) / kt_per;          // no empty slices
+  if (S < 2) return pl;
+  pl.nsplit = S;
+  pl.split_from = (int)from;
+  pl.kchunk = kt_per * BK;
+  pl.slab_floats = (tiles - from) * S * (long long)BM * BN;
+  return pl;
+}
+
 template <class T, int LAYOUT, int VEC, int EPI>
-int launch(const GemmParams& p, int nsplit, hipStream_t stream) {
+int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK;
   constexpr bool AKC = LAYOUT != GEMM_TN;
   constexpr bool BKC = LAYOUT == GEMM_NT;
@@ -531,9 +644,21 @@ int launch(const GemmParams& p, int nsplit, hipStream_t stream) {
     if (e != hipSuccess) return dgvit_set_error(DGVIT_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
+  GemmParams p = p0;
   const long long tiles = (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   DGVIT_CHECK_ARG(tiles > 0 && tiles < (1ll << 31), "gemm: bad tile count %lld", tiles);
-  dim3 grid((unsigned)tiles, 1, (unsigned)nsplit);
+  long long blocks = tiles;
+  p.nsplit = 1;
+  p.split_from = (int)tiles;
+  if (EPI != EPI_SPLITK && VEC == 4 && p.counters && p.slabs && p.evec && g_gemm_split) {
+    const int occ = (int)std::min<size_t>(8, (160 * 1024) / lds);
+    const GemmSplitPlan pl = split_plan(p.M, p.N, p.K, BM, BN, BK, occ);
+    if (pl.nsplit > 1 && pl.slab_floats <= p.slab_capacity && tiles <= p.counter_capacity) {
+      p.nsplit = pl.nsplit; p.split_from = pl.split_from; p.kchunk_split = pl.kchunk;
+      blocks = pl.split_from + (tiles - pl.split_from) * pl.nsplit;
+    }
+  }
+  dim3 grid((unsigned)blocks, 1, (unsigned)nsplit);
   const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, stream);
   hipLaunchKernelGGL(kern, grid, dim3(T::NT), lds, stream, p);
   profile_end(slot, stream);
@@ -544,19 +669,21 @@ int launch(const GemmParams& p, int nsplit, hipStream_t stream) {
 // tile_hint = BM*1000000 + BN*1000 + BK (e.g. 128128032), 0 = automatic
 #define DGVIT_TILES(X) X(128, 128, 32) X(128, 128, 16) X(64, 64, 32) X(64, 64, 64) X(128, 64, 32) X(64, 128, 32) X(128, 64, 16) X(64, 128, 16)
 
+// measured on MI355X at T = 25600 token rows (tools/gemm_shapes_bench.py, profiles/r01_b_gemm_tiles.txt):
+// weight gradients (long K, split over tokens) like the 128x128 tile; forward / data-gradient GEMMs are
+// tile-quantisation and prologue bound, so they take small tiles: wide outputs 64x128x16, narrow 64x64x32
+inline int auto_tile(int layout, int M, int N) {
+  if (layout == GEMM_TN) return (M >= 128 && N >= 128) ? 128128032 : 64064032;
+  return N >= 1024 ? 64128016 : 64064032;
+}
+
 template <int LAYOUT, int EPI>
 int pick_tile(const GemmParams& p, int nsplit, bool vec4, int tile_hint, hipStream_t stream) {
   if (!vec4) return launch<TileCfg<64, 64, 32>, LAYOUT, 1, EPI>(p, nsplit, stream);
   int choice = tile_hint;
   if (choice == 64) choice = 64064032;
   if (choice == 128) choice = 128128032;
-  if (choice == 0) {
-    // measured on MI355X at T = 25600 token rows (tools/gemm_shapes_bench.py, profiles/r01_b_gemm_tiles.txt):
-    // weight gradients (long K, split over tokens) like the 128x128 tile; forward / data-gradient GEMMs are
-    // tile-quantisation and prologue bound, so they take small tiles: wide outputs 64x128x16, narrow 64x64x32
-    if (LAYOUT == GEMM_TN) choice = (p.M >= 128 && p.N >= 128) ? 128128032 : 64064032;
-    else choice = p.N >= 1024 ? 64128016 : 64064032;
-  }
+  if (choice == 0) choice = auto_tile(LAYOUT, p.M, p.N);
 #define X(BM_, BN_, BK_) \
   if (choice == BM_ * 1000000 + BN_ * 1000 + BK_) return launch<TileCfg<BM_, BN_, BK_>, LAYOUT, 4, EPI>(p, nsplit, stream);
   DGVIT_TILES(X)
@@ -569,6 +696,18 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 }  // namespace
 
 int g_gemm_tile_hint = 0;  // test/bench override: 0 auto, 64, 128
+int g_gemm_split = 1;      // A/B knob: in-launch split-K of the forward / data-gradient GEMMs
+
+GemmSplitPlan gemm_split_plan(int layout, int M, int N, int K) {
+  GemmSplitPlan none = {};
+  none.nsplit = 1;
+  if (layout == GEMM_TN || M <= 0 || N <= 0 || K <= 0) return none;
+  const int c = auto_tile(layout, M, N);
+  const int BM = c / 1000000, BN = (c / 1000) % 1000, BK = c % 1000;
+  const bool akc = true, bkc = layout == GEMM_NT;
+  const size_t lds = 2 * (size_t)((akc ? BM * (BK + 4) : BK * (BM + 4)) + (bkc ? BN * (BK + 4) : BK * (BN + 4))) * sizeof(float);
+  return split_plan(M, N, K, BM, BN, BK, (int)std::min<size_t>(8, (160 * 1024) / lds));
+}
 
 int gemm_f32(int layout, int epi, const GemmParams& p, int nsplit, hipStream_t stream) {
   DGVIT_CHECK_ARG(p.A && p.B && p.C, "gemm: null operand");
@@ -603,22 +742,52 @@ int gemm_f32(int layout, int epi, const GemmParams& p, int nsplit, hipStream_t s
   return dgvit_set_error(DGVIT_ERR_ARG, "gemm: unsupported layout/epilogue %d/%d", layout, epi);
 }
 
+// ---- grouped deterministic reductions ----------------------------------------------------------------------------------
+void reduce_group_init(ReduceGroup& g) { g.njobs = 0; g.first_block[0] = 0; }
+
+// launch every queued job as ONE kernel (no-op when empty)
+int reduce_group_flush(ReduceGroup& g, hipStream_t stream) {
+  if (g.njobs == 0) return DGVIT_OK;
+  const int slot = profile_begin(PROF_OTHER, 0.0, stream);
+  hipLaunchKernelGGL(reduce_group_kernel, dim3((unsigned)g.first_block[g.njobs]), dim3(256), 0, stream, g);
+  profile_end(slot, stream);
+  g.njobs = 0;
+  DGVIT_CHECK_LAUNCH("reduce_group");
+  return DGVIT_OK;
+}
+
+// queue: out1 gets the first n1 sums, out2 (may be null when n1 == n) the remaining n - n1, of nslab slabs slab_stride floats apart.
+// Jobs that cannot take the float4 path (odd sizes / alignment: tiny head Linears) run at once on the scalar kernel.
+int reduce_group_add(ReduceGroup& g, const float* slabs, float* out1, long long n1, float* out2, long long n, int nslab,
+                     long long slab_stride, hipStream_t stream) {
+  DGVIT_CHECK_ARG(slabs && out1 && n > 0 && n1 > 0 && n1 <= n && nslab >= 1 && (n1 == n || out2), "reduce_slabs: bad arguments");
+  if (!(n % 4 == 0 && n1 % 4 == 0 && slab_stride % 4 == 0 && al16(slabs) && al16(out1) && (n1 == n || al16(out2)))) {
+    const int slot = profile_begin(PROF_OTHER, 0.0, stream);
+    hipLaunchKernelGGL(reduce_slabs_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slabs, out1, out2, n, n1,
+                       nslab, slab_stride);
+    profile_end(slot, stream);
+    DGVIT_CHECK_LAUNCH("reduce_slabs");
+    return DGVIT_OK;
+  }
+  if (g.njobs == DGVIT_REDUCE_JOBS) TRY_RG(reduce_group_flush(g, stream));
+  ReduceJob& job = g.job[g.njobs];
+  job.slabs = slabs; job.out1 = out1; job.out2 = out2;
+  job.n4 = n / 4; job.n14 = n1 / 4; job.nslab = nslab; job.stride4 = slab_stride / 4;
+  job.cw_log = (job.n4 <= 1024 && nslab >= 64) ? 4 : 6;   // few columns, many slabs: 16 slab groups per block
+  const long long blocks = (job.n4 + (1 << job.cw_log) - 1) >> job.cw_log;
+  DGVIT_CHECK_ARG(blocks + g.first_block[g.njobs] < (1ll << 30), "reduce_slabs: too many blocks");
+  g.first_block[g.njobs + 1] = g.first_block[g.njobs] + (int)blocks;
+  ++g.njobs;
+  return DGVIT_OK;
+}
+
 // out1 gets the first n1 sums, out2 (may be null when n1 == n) the remaining n - n1
 int reduce_slabs2(const float* slabs, float* out1, long long n1, float* out2, long long n, int nslab, long long slab_stride,
                   hipStream_t stream) {
-  DGVIT_CHECK_ARG(slabs && out1 && n > 0 && n1 > 0 && n1 <= n && nslab >= 1 && (n1 == n || out2), "reduce_slabs: bad arguments");
-  const int slot = profile_begin(PROF_OTHER, 0.0, stream);
-  if (n % 4 == 0 && n1 % 4 == 0 && slab_stride % 4 == 0 && al16(slabs) && al16(out1) && (n1 == n || al16(out2))) {
-    const long long n4 = n / 4;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((n4 + 63) / 64)), dim3(256), 0, stream, slabs, out1, out2, n4, n1 / 4,
-                       nslab, slab_stride);
-  } else {
-    hipLaunchKernelGGL(reduce_slabs_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slabs, out1, out2, n, n1,
-                       nslab, slab_stride);
-  }
-  profile_end(slot, stream);
-  DGVIT_CHECK_LAUNCH("reduce_slabs");
-  return DGVIT_OK;
+  ReduceGroup g;
+  reduce_group_init(g);
+  TRY_RG(reduce_group_add(g, slabs, out1, n1, out2, n, nslab, slab_stride, stream));
+  return reduce_group_flush(g, stream);
 }
 
 int reduce_slabs(const float* slabs, float* out, long long n, int nslab, long long slab_stride, hipStream_t stream) {

@@ -6,7 +6,7 @@
 int layernorm_fwd(const float*, const float*, const float*, float*, float*, float*, int, int, float, int, hipStream_t);
 int layernorm_bwd_blocks(int T);
 int layernorm_bwd(const float*, const float*, const float*, const float*, const float*, const float*, float*, float*, float*,
-                  float*, int, int, int, hipStream_t);
+                  float*, int, int, int, hipStream_t, ReduceGroup* grp = nullptr);
 int rmsnorm_fwd(const float*, long long, const float*, float*, int, int, hipStream_t);
 int rmsnorm_bwd_blocks(int B);
 int rmsnorm_bwd(const float*, const float*, long long, const float*, float*, long long, float*, float*, int, int, hipStream_t);
@@ -34,3 +34,4 @@ int noise_clip(const float*, const float*, float*, long long, float, unsigned lo
 int gaussian_blur_band(const float*, float*, float*, int, int, int, int, int, int, hipStream_t);
 int resize_bilinear(const float*, float*, int, int, int, int, int, float, hipStream_t);
 extern int g_gemm_tile_hint;
+extern int g_gemm_split;

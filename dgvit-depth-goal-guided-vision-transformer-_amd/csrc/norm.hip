@@ -221,16 +221,22 @@ static int layernorm_bwd_blocks_f32(int T) { return T < 2048 ? (T + 3) / 4 : 512
 
 // partial is [nb][2][D]: one pass reduces both halves (stride 2*D), first D sums -> dgamma, next D -> dbeta;
 // a null dgamma / dbeta (frozen parameter) is skipped
-static int ln_param_grads(const float* partial, float* dgamma, float* dbeta, int D, int nb, hipStream_t stream) {
-  if (dgamma && dbeta) return reduce_slabs2(partial, dgamma, D, dbeta, 2ll * D, nb, 2ll * D, stream);
-  if (dgamma) return reduce_slabs(partial, dgamma, D, nb, 2ll * D, stream);
-  if (dbeta) return reduce_slabs(partial + D, dbeta, D, nb, 2ll * D, stream);
-  return DGVIT_OK;
+// grp != null: the reduction is queued there (the caller flushes several reductions as one launch) instead of launched here
+static int ln_param_grads(const float* partial, float* dgamma, float* dbeta, int D, int nb, hipStream_t stream, ReduceGroup* grp) {
+  ReduceGroup local;
+  if (!grp) reduce_group_init(local);
+  ReduceGroup& g = grp ? *grp : local;
+  int rc = DGVIT_OK;
+  if (dgamma && dbeta) rc = reduce_group_add(g, partial, dgamma, D, dbeta, 2ll * D, nb, 2ll * D, stream);
+  else if (dgamma) rc = reduce_group_add(g, partial, dgamma, D, nullptr, D, nb, 2ll * D, stream);
+  else if (dbeta) rc = reduce_group_add(g, partial + D, dbeta, D, nullptr, D, nb, 2ll * D, stream);
+  if (rc || grp) return rc;
+  return reduce_group_flush(local, stream);
 }
 
 // partial must hold layernorm_bwd_blocks(T) * 2 * D floats; dgamma/dbeta are written (not accumulated)
 int layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
-                  float* dx, float* dgamma, float* dbeta, float* partial, int T, int D, int rs, hipStream_t stream) {
+                  float* dx, float* dgamma, float* dbeta, float* partial, int T, int D, int rs, hipStream_t stream, ReduceGroup* grp) {
   DGVIT_CHECK_ARG(dy && x && mean && rstd && gamma && dx && partial, "layernorm_bwd: null pointer");
   DGVIT_CHECK_ARG(T > 0 && D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bwd: D=%d must be a multiple of 4, <= 1024", D);
   const int nb = layernorm_bwd_blocks_f32(T);
@@ -244,7 +250,7 @@ int layernorm_bwd(const float* dy, const float* x, const float* mean, const floa
   else LNB(4);
 #undef LNB
   DGVIT_CHECK_LAUNCH("layernorm_bwd");
-  return ln_param_grads(partial, dgamma, dbeta, D, nb, stream);
+  return ln_param_grads(partial, dgamma, dbeta, D, nb, stream, grp);
 }
 
 // bf16 configuration: dy bf16; dx fp32 (+ optional bf16 copy dxb)
@@ -265,7 +271,7 @@ int layernorm_bwd_bf16(const bf16_t* dy, const float* x, const float* mean, cons
 #undef LNB
   profile_end(slot, stream);
   DGVIT_CHECK_LAUNCH("layernorm_bwd_bf16");
-  return ln_param_grads(partial, dgamma, dbeta, D, nb, stream);
+  return ln_param_grads(partial, dgamma, dbeta, D, nb, stream, nullptr);
 }
 
 int rmsnorm_fwd(const float* x, long long ldx, const float* g, float* y, int B, int D, hipStream_t stream) {

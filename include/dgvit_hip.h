@@ -135,6 +135,13 @@ void dgvit_set_prune_last_layer(int on);
  * data-gradient chain: +5 % frames/s at C3 on MI355X, but concurrent kernels stretch each other's durations, so
  * per-kernel timings (dgvit_profile_*, rocprof) stop being interpretable.  0 keeps everything on the caller's stream. */
 void dgvit_set_wgrad_overlap(int on);
+/* A/B knob (default 1): dgvit_got_backward sums a layer's split-K weight-gradient slabs and LayerNorm partials in ONE grouped
+ * launch per layer; 0 = one reduction launch behind every producer (the round-1 schedule).  Results are bit-identical. */
+void dgvit_set_grouped_reduce(int on);
+/* A/B knob (default 1): forward / data-gradient GEMMs with far fewer output tiles than the chip has workgroup slots, or with a
+ * nearly empty last round of tiles, are split over K inside the launch (partial tiles + last-arriver epilogue, deterministic).
+ * 0 = one workgroup per output tile.  Results agree to fp32 rounding (the order of the k-sum changes). */
+void dgvit_set_gemm_split(int on);
 
 /* nn.LayerNorm(D), eps 1e-5 (GoalFormer.py:34,37): y, and the per-row mean / rstd saved for backward */
 int dgvit_layernorm_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

@@ -25,3 +25,14 @@ def fwd_flops_per_frame(image, patch, dim, depth, heads, dim_head=64, mlp_dim=20
     P = (image[0] // patch[0]) * (image[1] // patch[1])
     pd, N, I = patch[0] * patch[1], P + 1, heads * dim_head
     return 2.0 * P * pd * dim + depth * (2.0 * N * dim * 3 * I + 4.0 * N * N * I + 2.0 * N * I * dim + 4.0 * N * dim * mlp_dim)
+
+
+def fwd_flops_per_frame_executed(image, patch, dim, depth, heads, dim_head=64, mlp_dim=2048, prune_last=True):
+    """The FLOPs the schedule really executes: with the last block pruned to token 0 (K and V for every token,
+    Q / attention / to_out / feed-forward for one row per frame) the last layer costs
+    2*N*D*2I (K, V) + 2*D*I (Q) + 4*N*I (one query row) + 2*I*D + 4*D*M instead of the dense layer."""
+    P = (image[0] // patch[0]) * (image[1] // patch[1])
+    pd, N, I = patch[0] * patch[1], P + 1, heads * dim_head
+    layer = 2.0 * N * dim * 3 * I + 4.0 * N * N * I + 2.0 * N * I * dim + 4.0 * N * dim * mlp_dim
+    last = 2.0 * N * dim * 2 * I + 2.0 * dim * I + 4.0 * N * I + 2.0 * I * dim + 4.0 * dim * mlp_dim
+    return 2.0 * P * pd * dim + (depth - 1) * layer + (last if prune_last else layer)

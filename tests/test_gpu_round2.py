@@ -558,3 +558,50 @@ def test_flat_adam_parameter_subsets_and_late_gradients(amd):
     oa2 = FlatAdam(subset(a), lr=3e-3)
     oa2.load_state_dict(sd)
     assert [None if s is None else s["step"] for s in oa2.state_dict()["state"]] == steps
+
+
+# ------------------------------------------------------------------------------------------------ in-launch split-K GEMM
+@pytest.mark.parametrize("layout,epi,M,N,K", [
+    (0, 0, 2080, 64, 2048),     # shipped model, B = 32: 33 tiles of 64 x 64 against 1024 workgroup slots
+    (0, 0, 65, 64, 2048),       # single frame
+    (0, 0, 33, 64, 300),        # ragged M and K, few k-tiles per slice
+    (1, 0, 2080, 64, 2048),     # data gradient of fc1
+    (0, 3, 130, 128, 1000),     # ReLU epilogue on the split path
+    (1, 2, 200, 64, 1024),      # GELU' epilogue (aux read by the last arriver)
+    (0, 0, 25600, 256, 2048),   # C3: 1600 tiles = 6.25 per CU, only the last 64 tiles are split
+    (1, 0, 25600, 256, 1536),
+])
+def test_gemm_in_launch_split_k(amd, layout, epi, M, N, K):
+    """Partial tiles + last-arriver epilogue must give the unsplit kernel's result (to fp32 summation-order rounding), the same
+    bits on every run, and leave the arrival counters zero (a second call on the same scratch works)."""
+    from dgvit_amd import functional as F, _lib
+    lib = _lib.load()
+    assert lib.dgvit_gemm_scratch_floats(layout, M, N, K) > 0, "this shape is supposed to take the split path"
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn(N, K, generator=g) if layout == 0 else torch.randn(K, N, generator=g)).cuda()
+    bias = torch.randn(N, generator=g).cuda() if layout == 0 else None
+    res = torch.randn(M, N, generator=g).cuda() if (layout == 0 and epi == 0) else None
+    aux = torch.randn(M, N, generator=g).cuda() if epi == 2 else None
+    run = lambda: F.op_gemm(layout, epi, A, B, M, N, K, bias=bias, res=res, aux=aux)
+    y1, y2 = run(), run()
+    assert torch.equal(y1, y2), "split-K result is not reproducible"
+    lib.dgvit_set_gemm_split(0)
+    try:
+        y0 = run()
+    finally:
+        lib.dgvit_set_gemm_split(1)
+    ref = A.double().cpu() @ (B.double().cpu().T if layout == 0 else B.double().cpu())
+    if bias is not None:
+        ref = ref + bias.double().cpu()
+    if res is not None:
+        ref = ref + res.double().cpu()
+    if epi == 3:
+        ref = ref.clamp_min(0)
+    if epi == 2:
+        a = aux.double().cpu()
+        ref = ref * (0.5 * (1 + torch.erf(a / 2 ** 0.5)) + a * torch.exp(-0.5 * a * a) / (2 * np.pi) ** 0.5)
+    tol = 2e-4 * K ** 0.5
+    assert (y1.double().cpu() - ref).abs().max().item() <= tol
+    assert (y0.double().cpu() - ref).abs().max().item() <= tol
+    assert (y1 - y0).abs().max().item() <= 1e-5 * K ** 0.5 * max(1.0, float(ref.abs().max()))
