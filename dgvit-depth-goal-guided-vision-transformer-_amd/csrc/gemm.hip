@@ -486,8 +486,13 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
     }
     __syncthreads();
     if (slab) {
-      for (int rr = rr0; rr < CROWS; rr += RPP)
-        *reinterpret_cast<float4*>(slab + (ch * CROWS + rr) * BN + cc) = *reinterpret_cast<const float4*>(smem + rr * CS + cc);
+      // write-through (sc1) stores: the partial tile leaves this XCD's L2 at once, so no release fence (an L2 write-back of
+      // every dirty line the other workgroups' C stores left there) is needed before the ticket
+      const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, BM * BN * 4, 0x00020000);
+      for (int rr = rr0; rr < CROWS; rr += RPP) {
+        const float4 t = *reinterpret_cast<const float4*>(smem + rr * CS + cc);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), srs, (unsigned)(((ch * CROWS + rr) * BN + cc) * 4), 0, 16);
+      }
     } else if (n < p.N) {
       for (int rr = rr0; rr < CROWS; rr += RPP) {
         const int m = m0 + ch * CROWS + rr;
@@ -500,13 +505,13 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
     if (ch + 1 < NCHUNK) __syncthreads();
   }
   if (EPI != EPI_SPLITK && nz > 1) {
-    // publish the slab, take a ticket; placement-independent agent-scope release / acquire (cdna_hip_programming.md, Guideline 16)
+    // publish the slab, take a ticket (cdna_hip_programming.md Guideline 16, recipe R1): write-through payload, every storing
+    // wave drains its stores, barrier, ONE lane adds to the tile's counter; the last arriver acquires (agent scope) before
+    // anybody reads the other slices.  Placement independent: nothing assumes which CU / XCD ran which slice.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem);
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int ticket = __hip_atomic_fetch_add(p.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = ticket == nz - 1;
       if (last) {
