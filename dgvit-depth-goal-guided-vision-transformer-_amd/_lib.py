@@ -20,6 +20,11 @@ class dgvit_config(Structure):
                 ("depth", c_int), ("heads", c_int), ("dim_head", c_int), ("mlp_dim", c_int), ("pool_mean", c_int)]
 
 
+class dgvit_mlp_desc(Structure):
+    _fields_ = [("batch", c_int), ("nseg", c_int), ("kx", c_int * 3), ("ldx", c_int * 3), ("n1", c_int), ("n2", c_int), ("n3", c_int),
+                ("towers", c_int), ("heads3", c_int)]
+
+
 NUM_GLOBAL_PARAMS = 4
 PARAMS_PER_LAYER = 11
 ABI_VERSION = 5
@@ -41,6 +46,11 @@ SIGNATURES = {
     "dgvit_linear_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dgvit_linear_backward_scratch_floats": (_LL, [_I, _I, _I]),
     "dgvit_linear_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
+    "dgvit_mlp_head_forward": (_I, [POINTER(dgvit_mlp_desc), _TABLE, _TABLE, _P, _P, _P, _P]),
+    "dgvit_mlp_head_backward_scratch_floats": (_LL, [POINTER(dgvit_mlp_desc)]),
+    "dgvit_mlp_head_backward": (_I, [POINTER(dgvit_mlp_desc), _TABLE, _TABLE, _P, _P, _TABLE, _TABLE, _TABLE, _P, _LL, _P]),
+    "dgvit_tanh_gaussian_forward": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _I, _I, _P]),
+    "dgvit_tanh_gaussian_backward": (_I, [_P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dgvit_gemm_scratch_floats": (_LL, [_I, _I, _I, _I]),
     "dgvit_gemm": (_I, [_I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P, _LL, _P]),
     "dgvit_set_gemm_tile": (None, [_I]),

@@ -9,7 +9,8 @@ from torch import nn
 from torch.distributions import Normal
 
 from . import functional as F_
-from .sac_networks import LOG_SIG_MAX, LOG_SIG_MIN, epsilon, weights_init_, _lin, _action_affine
+from . import sac_networks as _S
+from .sac_networks import LOG_SIG_MAX, LOG_SIG_MIN, epsilon, weights_init_, _lin, _head, _action_affine
 
 
 class _ConvStack(nn.Module):
@@ -43,9 +44,7 @@ class QNetwork(_ConvStack):
         istate, pstate, a = inp
         x1 = self._features(istate)
         x2 = _lin(self.fc_embed, pstate, relu=True)
-        x = torch.cat([x1, x2, a], dim=1)
-        q1 = _lin(self.fc3, _lin(self.fc2, _lin(self.fc1, x, True), True))
-        q2 = _lin(self.fc31, _lin(self.fc21, _lin(self.fc11, x, True), True))
+        (q1,), (q2,) = _head([x1, x2, a], [(self.fc1, self.fc2, [self.fc3]), (self.fc11, self.fc21, [self.fc31])])
         return q1, q2
 
 
@@ -63,25 +62,19 @@ class GaussianPolicy(_ConvStack):
         self.apply(weights_init_)
         self.action_scale, self.action_bias = _action_affine(action_space)
 
-    def forward(self, inp):
+    def _head_outputs(self, inp):
         istate, pstate = inp
-        x = torch.cat([self._features(istate), _lin(self.fc_embed, pstate)], dim=1)   # no activation on the goal (:299)
-        x = _lin(self.fc2, _lin(self.fc1, x, True), True)
-        mean = _lin(self.mean_linear, x)
-        log_std = torch.clamp(_lin(self.log_std_linear, x), min=LOG_SIG_MIN, max=LOG_SIG_MAX)
-        return mean, log_std
+        xs = [self._features(istate), _lin(self.fc_embed, pstate)]                    # no activation on the goal (:299)
+        ((mean, log_std_raw),) = _head(xs, [(self.fc1, self.fc2, [self.mean_linear, self.log_std_linear])])
+        return mean, log_std_raw
+
+    def forward(self, inp):
+        mean, log_std_raw = self._head_outputs(inp)
+        return mean, torch.clamp(log_std_raw, min=LOG_SIG_MIN, max=LOG_SIG_MAX)
 
     def sample(self, inp):
-        mean, log_std = self.forward(inp)
-        std = log_std.exp()
-        normal = Normal(mean, std, validate_args=False)
-        x_t = normal.rsample()
-        y_t = torch.tanh(x_t)
-        action = y_t * self.action_scale + self.action_bias
-        log_prob = normal.log_prob(x_t) - torch.log(self.action_scale * (1 - y_t.pow(2)) + epsilon)
-        log_prob = log_prob.sum(1, keepdim=True)
-        mean = torch.tanh(mean) * self.action_scale + self.action_bias
-        return action, log_prob, mean
+        mean, log_std_raw = self._head_outputs(inp)
+        return _S._tanh_gaussian(self, mean, log_std_raw)
 
     def to(self, device):
         self.action_scale = self.action_scale.to(device)

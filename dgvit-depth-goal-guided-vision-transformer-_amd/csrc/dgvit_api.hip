@@ -591,6 +591,30 @@ extern "C" int dgvit_linear_backward(const float* dy, const float* x, const floa
   return DGVIT_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- fused MLP heads
+extern "C" int dgvit_mlp_head_forward(const dgvit_mlp_desc* desc, const float* const* in, const float* const* params, float* h1,
+                                      float* h2, float* y, void* stream) {
+  return mlp_head_forward(desc, in, params, h1, h2, y, (hipStream_t)stream);
+}
+extern "C" long long dgvit_mlp_head_backward_scratch_floats(const dgvit_mlp_desc* desc) { return mlp_head_backward_scratch(desc); }
+extern "C" int dgvit_mlp_head_backward(const dgvit_mlp_desc* desc, const float* const* in, const float* const* params, const float* h1,
+                                       const float* h2, const float* const* dy, float* const* din, float* const* dparams, float* scratch,
+                                       long long scratch_floats, void* stream) {
+  return mlp_head_backward(desc, in, params, h1, h2, dy, din, dparams, scratch, scratch_floats, (hipStream_t)stream);
+}
+
+extern "C" int dgvit_tanh_gaussian_forward(const float* mean, const float* log_std_raw, const float* eps, const float* scale,
+                                           const float* bias, int scale_n, float ls_min, float ls_max, float* action, float* log_prob,
+                                           float* tanh_mean, int B, int A, void* stream) {
+  return tanh_gaussian_forward(mean, log_std_raw, eps, scale, bias, scale_n, ls_min, ls_max, action, log_prob, tanh_mean, B, A, (hipStream_t)stream);
+}
+extern "C" int dgvit_tanh_gaussian_backward(const float* mean, const float* log_std_raw, const float* eps, const float* scale, int scale_n,
+                                            float ls_min, float ls_max, const float* d_action, const float* d_log_prob,
+                                            const float* d_tanh_mean, float* dmean, float* dlog_std_raw, int B, int A, void* stream) {
+  return tanh_gaussian_backward(mean, log_std_raw, eps, scale, scale_n, ls_min, ls_max, d_action, d_log_prob, d_tanh_mean, dmean, dlog_std_raw, B, A,
+                                (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------- operator exports
 extern "C" long long dgvit_gemm_scratch_floats(int layout, int M, int N, int K) {
   if (layout != GEMM_TN) {   // in-launch split-K: arrival counters (one per tile) + partial tiles; 0 when the shape is not split

@@ -251,6 +251,142 @@ def linear(x, weight, bias=None, relu=False):
     return _Linear.apply(x, weight, bias, 1 if relu else 0)
 
 
+# ------------------------------------------------------------------------------------------------ fused MLP heads
+def _mlp_desc(batch, xs, n1, n2, n3, towers, heads3):
+    d = _lib.dgvit_mlp_desc()
+    d.batch, d.nseg, d.n1, d.n2, d.n3, d.towers, d.heads3 = batch, len(xs), n1, n2, n3, towers, heads3
+    for i, x in enumerate(xs):
+        d.kx[i], d.ldx[i] = x.shape[1], x.stride(0)
+    return d
+
+
+class _MlpHead(torch.autograd.Function):
+    """y[t, j] = W3[t][j] relu(W2[t] relu(W1[t] cat(xs) + b1[t]) + b2[t]) + b3[t][j] as one HIP launch forward and one backward
+    (dgvit_mlp_head_forward / _backward): the SAC heads of got_sac_network.py:114-121, 230-235, 433-435."""
+
+    @staticmethod
+    def forward(ctx, nseg, towers, heads3, *tensors):
+        lib = _lib.load()
+        xs = [_dev(t, f"head input {i}") for i, t in enumerate(tensors[:nseg])]
+        params = [_dev(t, f"head parameter {i}") for i, t in enumerate(tensors[nseg:])]
+        per = 4 + 2 * heads3
+        if len(params) != towers * per:
+            raise DgvitError(f"mlp_head: expected {towers * per} parameter tensors, got {len(params)}")
+        B = xs[0].shape[0]
+        n1, n2, n3 = params[0].shape[0], params[2].shape[0], params[4].shape[0]
+        K0 = sum(x.shape[1] for x in xs)
+        for t in range(towers):
+            q = params[t * per:(t + 1) * per]
+            ok = (q[0].shape == (n1, K0) and q[1].shape == (n1,) and q[2].shape == (n2, n1) and q[3].shape == (n2,)
+                  and all(q[4 + 2 * j].shape == (n3, n2) and q[5 + 2 * j].shape == (n3,) for j in range(heads3)))
+            if not ok or any(x.dim() != 2 or x.shape[0] != B or x.stride(1) != 1 for x in xs):
+                raise DgvitError("mlp_head: inconsistent input / parameter shapes")
+        desc = _mlp_desc(B, xs, n1, n2, n3, towers, heads3)
+        dev = xs[0].device
+        h1 = torch.empty(towers, B, n1, dtype=torch.float32, device=dev)
+        h2 = torch.empty(towers, B, n2, dtype=torch.float32, device=dev)
+        y = torch.empty(towers, heads3, B, n3, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.dgvit_mlp_head_forward(ctypes.byref(desc), _table(xs), _table(params), _ptr(h1), _ptr(h2), _ptr(y), _stream())
+        _lib.check(rc, "dgvit_mlp_head_forward")
+        ctx.meta = (nseg, towers, heads3, n1, n2, n3)
+        ctx.save_for_backward(h1, h2, *xs, *params)
+        ctx.set_materialize_grads(False)      # an unused output (e.g. log_std under a loss on the mean only) arrives as None
+        return tuple(y[t, j] for t in range(towers) for j in range(heads3))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        lib = _lib.load()
+        nseg, towers, heads3, n1, n2, n3 = ctx.meta
+        h1, h2, *rest = ctx.saved_tensors
+        xs, params = rest[:nseg], rest[nseg:]
+        dys = [None if g is None else _dev(g, "dy") for g in dys]
+        B, dev = xs[0].shape[0], xs[0].device
+        need = ctx.needs_input_grad[3:]
+        if all(g is None for g in dys):
+            return (None,) * (3 + nseg + len(params))
+        din = [torch.empty(B, x.shape[1], dtype=torch.float32, device=dev) if need[i] else None for i, x in enumerate(xs)]
+        per = 4 + 2 * heads3
+        dpar = []
+        for i, p in enumerate(params):
+            t, q = divmod(i, per)
+            unused = q >= 4 and dys[t * heads3 + (q - 4) // 2] is None     # third layer whose output nobody used: no gradient,
+            dpar.append(torch.empty_like(p) if need[nseg + i] and not unused else None)   # as for an nn.Linear outside the graph
+        desc = _mlp_desc(B, xs, n1, n2, n3, towers, heads3)
+        nsc = lib.dgvit_mlp_head_backward_scratch_floats(ctypes.byref(desc))
+        scratch = torch.empty(max(int(nsc), 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.dgvit_mlp_head_backward(ctypes.byref(desc), _table(xs), _table(params), _ptr(h1), _ptr(h2), _grad_table(dys), _grad_table(din),
+                                             _grad_table(dpar), _ptr(scratch), scratch.numel(), _stream())
+        _lib.check(rc, "dgvit_mlp_head_backward")
+        return (None, None, None, *din, *dpar)
+
+
+def mlp_head_supported(xs, towers):
+    """The fused head kernels take hidden widths that are multiples of 32 up to 128, at most 4 outputs and 512 inputs."""
+    if not (1 <= len(xs) <= 3 and 1 <= len(towers) <= 2):
+        return False
+    l1, l2, l3s = towers[0]
+    n1, n2, n3 = l1.weight.shape[0], l2.weight.shape[0], l3s[0].weight.shape[0]
+    return (n1 % 32 == 0 and n2 % 32 == 0 and n1 <= 128 and n2 <= 128 and n3 <= 4 and 1 <= len(l3s) <= 2
+            and sum(x.shape[1] for x in xs) <= 512 and all(x.shape[0] > 0 for x in xs))
+
+
+def mlp_head(xs, towers):
+    """Fused SAC head.  ``xs``: 1-3 (B, k_i) tensors that the reference concatenates along dim 1; ``towers``: 1 or 2 tuples
+    ``(fc1, fc2, [third layers])`` of nn.Linear modules.  Returns [[y (B, n3) of third layer j of tower t]]."""
+    flat = []
+    for l1, l2, l3s in towers:
+        flat += [l1.weight, l1.bias, l2.weight, l2.bias]
+        for l3 in l3s:
+            flat += [l3.weight, l3.bias]
+    xs = [x if x.stride(-1) == 1 else x.contiguous() for x in xs]
+    nh = len(towers[0][2])
+    ys = _MlpHead.apply(len(xs), len(towers), nh, *xs, *flat)
+    return [list(ys[t * nh:(t + 1) * nh]) for t in range(len(towers))]
+
+
+class _TanhGaussian(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mean, log_std_raw, eps, scale, bias, lo, hi):
+        lib = _lib.load()
+        mean, lsr, eps = _dev(mean, "mean"), _dev(log_std_raw, "log_std"), _dev(eps, "eps")
+        scale, bias = _dev(scale.reshape(-1), "action_scale"), _dev(bias.reshape(-1), "action_bias")
+        B, A = mean.shape
+        if lsr.shape != (B, A) or eps.shape != (B, A) or scale.numel() not in (1, A) or bias.numel() != scale.numel():
+            raise DgvitError("tanh_gaussian_sample: mean, log_std and eps must be (B, A); scale / bias 1 or A values")
+        action, tmean = torch.empty_like(mean), torch.empty_like(mean)
+        logp = torch.empty(B, 1, dtype=torch.float32, device=mean.device)
+        with torch.cuda.device(mean.device):
+            rc = lib.dgvit_tanh_gaussian_forward(_ptr(mean), _ptr(lsr), _ptr(eps), _ptr(scale), _ptr(bias), scale.numel(), float(lo), float(hi),
+                                                 _ptr(action), _ptr(logp), _ptr(tmean), B, A, _stream())
+        _lib.check(rc, "dgvit_tanh_gaussian_forward")
+        ctx.lohi = (float(lo), float(hi))
+        ctx.save_for_backward(mean, lsr, eps, scale)
+        return action, logp, tmean
+
+    @staticmethod
+    def backward(ctx, dact, dlp, dtm):
+        lib = _lib.load()
+        mean, lsr, eps, scale = ctx.saved_tensors
+        B, A = mean.shape
+        dact = None if dact is None else _dev(dact, "d_action")
+        dlp = None if dlp is None else _dev(dlp, "d_log_prob")
+        dtm = None if dtm is None else _dev(dtm, "d_tanh_mean")
+        dmean, dls = torch.empty_like(mean), torch.empty_like(mean)
+        with torch.cuda.device(mean.device):
+            rc = lib.dgvit_tanh_gaussian_backward(_ptr(mean), _ptr(lsr), _ptr(eps), _ptr(scale), scale.numel(), ctx.lohi[0], ctx.lohi[1],
+                                                  _ptr(dact), _ptr(dlp), _ptr(dtm), _ptr(dmean), _ptr(dls), B, A, _stream())
+        _lib.check(rc, "dgvit_tanh_gaussian_backward")
+        return dmean, dls, None, None, None, None, None
+
+
+def tanh_gaussian_sample(mean, log_std_raw, eps, scale, bias, ls_min, ls_max):
+    """(action, log_prob (B, 1), tanh_mean) of got_sac_network.py:238-251 from the head outputs and a standard-normal draw, one
+    HIP launch forward and one backward; ``log_std_raw`` is the un-clamped log_std_linear output (the clamp is applied inside)."""
+    return _TanhGaussian.apply(mean, log_std_raw, eps, scale, bias, ls_min, ls_max)
+
+
 # ------------------------------------------------------------------------------------------------ operator-level helpers
 def op_gemm(layout, epilogue, A, B, M, N, K, bias=None, res=None, aux=None, want_c2=False):
     lib = _lib.load()

@@ -36,6 +36,41 @@ def _lin(layer, x, relu=False):
     return F_.linear(x, layer.weight, layer.bias, relu=relu)
 
 
+def _head(xs, towers):
+    """relu(fc1) -> relu(fc2) -> third layer(s) on cat(xs): ONE fused HIP launch each way when the widths fit the fused head
+    kernel (every network of the reference does), else the same arithmetic as a chain of MFMA GEMM launches.
+    Returns [[y of third layer j of tower t]]."""
+    if xs[0].shape[0] > 0 and F_.mlp_head_supported(xs, towers):
+        return F_.mlp_head(xs, towers)
+    x = xs[0] if len(xs) == 1 else torch.cat(xs, dim=1)
+    out = []
+    for l1, l2, l3s in towers:
+        h = _lin(l2, _lin(l1, x, True), True)
+        out.append([_lin(l3, h) for l3 in l3s])
+    return out
+
+
+def _standard_normal(like):
+    """The N(0, 1) draw inside Normal.rsample (got_sac_network.py:242), made on the device.  Tests replace this function to
+    inject the reference run's own draw."""
+    return torch.randn_like(like)
+
+
+def _tanh_gaussian(module, mean, log_std_raw):
+    """sample() of got_sac_network.py:238-251 / :310-321 from the head outputs: (action, log_prob, tanh(mean) * scale + bias)."""
+    if mean.shape[0] == 0:       # empty batch: the reference's torch ops accept it
+        log_std = torch.clamp(log_std_raw, min=LOG_SIG_MIN, max=LOG_SIG_MAX)
+        normal = Normal(mean, log_std.exp(), validate_args=False)
+        x_t = normal.rsample()
+        y_t = torch.tanh(x_t)
+        log_prob = (normal.log_prob(x_t) - torch.log(module.action_scale * (1 - y_t.pow(2)) + epsilon)).sum(1, keepdim=True)
+        return y_t * module.action_scale + module.action_bias, log_prob, torch.tanh(mean) * module.action_scale + module.action_bias
+    scale, bias = module.action_scale, module.action_bias
+    if scale.device != mean.device:          # module moved with .cuda() instead of the reference's .to(): follow it once
+        module.action_scale, module.action_bias = scale, bias = scale.to(mean.device), bias.to(mean.device)
+    return F_.tanh_gaussian_sample(mean, log_std_raw, _standard_normal(mean), scale, bias, LOG_SIG_MIN, LOG_SIG_MAX)
+
+
 def _action_affine(action_space):
     if action_space is None:
         return torch.tensor(1.), torch.tensor(0.)
@@ -72,9 +107,7 @@ class GoTQNetwork(nn.Module):
         istate, pstate, a = inp
         goal = _lin(self.fc_embed, pstate, relu=True)          # ReLU on the goal embedding (:111)
         feat = self.trans(istate, goal)
-        x = torch.cat([feat.view(feat.size(0), -1), a], dim=1)
-        q1 = _lin(self.fc3, _lin(self.fc2, _lin(self.fc1, x, True), True))
-        q2 = _lin(self.fc31, _lin(self.fc21, _lin(self.fc11, x, True), True))
+        (q1,), (q2,) = _head([feat.view(feat.size(0), -1), a], [(self.fc1, self.fc2, [self.fc3]), (self.fc11, self.fc21, [self.fc31])])
         return q1, q2
 
 
@@ -109,29 +142,22 @@ class GoTPolicy(nn.Module):
             _, _, action = self.sample([istate, pstate])
         return action.detach().squeeze(0).cpu().numpy()
 
-    def forward(self, inp):
+    def _head_outputs(self, inp):
         istate, pstate = inp
         goal = _lin(self.fc_embed, pstate)                      # no activation (:226)
         feat = self.trans(istate, goal)
-        x = _lin(self.fc2, _lin(self.fc1, feat, True), True)
-        mean = _lin(self.mean_linear, x)
-        log_std = torch.clamp(_lin(self.log_std_linear, x), min=LOG_SIG_MIN, max=LOG_SIG_MAX)
-        return mean, log_std
+        ((mean, log_std_raw),) = _head([feat], [(self.fc1, self.fc2, [self.mean_linear, self.log_std_linear])])
+        return mean, log_std_raw
+
+    def forward(self, inp):
+        mean, log_std_raw = self._head_outputs(inp)
+        return mean, torch.clamp(log_std_raw, min=LOG_SIG_MIN, max=LOG_SIG_MAX)
 
     def sample(self, inp):
-        mean, log_std = self.forward(inp)
-        std = log_std.exp()
-        # validate_args=False: the default argument check is a device->host sync on every call (and cannot be
-        # captured into a HIP graph); the arithmetic is the reference's (got_sac_network.py:240-250)
-        normal = Normal(mean, std, validate_args=False)
-        x_t = normal.rsample()
-        y_t = torch.tanh(x_t)
-        action = y_t * self.action_scale + self.action_bias
-        log_prob = normal.log_prob(x_t)
-        log_prob = log_prob - torch.log(self.action_scale * (1 - y_t.pow(2)) + epsilon)
-        log_prob = log_prob.sum(1, keepdim=True)
-        mean = torch.tanh(mean) * self.action_scale + self.action_bias
-        return action, log_prob, mean
+        """(action, log_prob, tanh(mean)) of got_sac_network.py:238-251: clamp, exp, rsample, tanh and the tanh-corrected Gaussian
+        log-density as ONE HIP launch behind the head (no Normal object: its argument check alone is a host sync per call)."""
+        mean, log_std_raw = self._head_outputs(inp)
+        return _tanh_gaussian(self, mean, log_std_raw)
 
     def to(self, device):
         self.action_scale = self.action_scale.to(device)
@@ -158,8 +184,8 @@ class DeterministicGoTPolicy(nn.Module):
         istate, pstate = inp
         goal = _lin(self.fc_embed, pstate)
         feat = self.trans(istate, goal)
-        x = _lin(self.fc2, _lin(self.fc1, feat.view(feat.size(0), -1), True), True)
-        return torch.tanh(_lin(self.mean_linear, x)) * self.action_scale + self.action_bias
+        ((mean,),) = _head([feat.view(feat.size(0), -1)], [(self.fc1, self.fc2, [self.mean_linear])])
+        return torch.tanh(mean) * self.action_scale + self.action_bias
 
     def sample(self, inp):
         mean = self.forward(inp)

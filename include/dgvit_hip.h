@@ -114,6 +114,43 @@ int dgvit_linear_backward(const float* dy, const float* x, const float* w, const
                           void* stream);
 
 /* ----------------------------------------------------------------------------------------------
+ * Fused MLP heads (got_sac_network.py:114-121 twin Q, :230-235 policy, :433-435 deterministic policy, CNN twins :157-166, :303-307):
+ *     y_j = W3_j relu(W2 relu(W1 cat(x_0 .. x_{nseg-1}) + b1) + b2) + b3_j ,  j < heads3,  for `towers` independent towers
+ * one launch forward, one backward (+ one grouped reduction when batch > 32), instead of one GEMM / mask / split-K / reduction
+ * launch per Linear.  A policy head = 1 tower, 2 third layers (mean_linear, log_std_linear); a twin-Q head = 2 towers
+ * (fc1,fc2,fc3 | fc11,fc21,fc31) over the same concatenated input.  n1, n2: multiples of 32 up to 128; n3 <= 4; sum kx <= 512.
+ *   in[s]     : (batch, kx[s]) with row stride ldx[s]          (the torch.cat of the reference is never materialised)
+ *   params    : per tower  W1 (n1, K0), b1, W2 (n2, n1), b2, then per third layer W3 (n3, n2), b3
+ *   h1, h2    : (towers, batch, n1 / n2) post-ReLU activations, kept for the backward
+ *   y         : (towers, heads3, batch, n3)
+ *   dy        : towers * heads3 pointers to (batch, n3) gradients of the single outputs; NULL = that output is unused: it
+ *               contributes nothing and its third layer gets no gradient (like an nn.Linear outside the autograd graph)
+ *   din[s]    : (batch, kx[s]) dense, NULL to skip;  dparams: like params, NULL entries skipped (written, not accumulated)
+ * -------------------------------------------------------------------------------------------- */
+typedef struct dgvit_mlp_desc {
+  int batch, nseg, kx[3], ldx[3];
+  int n1, n2, n3, towers, heads3;
+} dgvit_mlp_desc;
+int dgvit_mlp_head_forward(const dgvit_mlp_desc* desc, const float* const* in, const float* const* params, float* h1, float* h2,
+                           float* y, void* stream);
+long long dgvit_mlp_head_backward_scratch_floats(const dgvit_mlp_desc* desc);
+int dgvit_mlp_head_backward(const dgvit_mlp_desc* desc, const float* const* in, const float* const* params, const float* h1,
+                            const float* h2, const float* const* dy, float* const* din, float* const* dparams, float* scratch,
+                            long long scratch_floats, void* stream);
+
+/* tanh-Gaussian action sampling of GoTPolicy.sample / GaussianPolicy.sample (got_sac_network.py:238-251, 310-321) in one launch:
+ *   ls = clamp(log_std_raw, ls_min, ls_max); x = mean + exp(ls) * eps; y = tanh(x); action = y * scale + bias;
+ *   log_prob (B) = sum_a [Normal(mean, exp(ls)).log_prob(x) - log(scale * (1 - y^2) + 1e-6)];  tanh_mean = tanh(mean) * scale + bias.
+ * mean, log_std_raw, eps, action, tanh_mean: (B, A); scale, bias: `scale_n` = 1 (scalar) or A values; eps ~ N(0, 1) from the caller.
+ * backward: gradients of action / log_prob / tanh_mean (NULL = none) -> dmean, dlog_std_raw (the clamp's mask included). */
+int dgvit_tanh_gaussian_forward(const float* mean, const float* log_std_raw, const float* eps, const float* scale, const float* bias,
+                                int scale_n, float ls_min, float ls_max, float* action, float* log_prob, float* tanh_mean, int B,
+                                int A, void* stream);
+int dgvit_tanh_gaussian_backward(const float* mean, const float* log_std_raw, const float* eps, const float* scale, int scale_n,
+                                 float ls_min, float ls_max, const float* d_action, const float* d_log_prob, const float* d_tanh_mean,
+                                 float* dmean, float* dlog_std_raw, int B, int A, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
  * Per-operator entry points (used by the encoder above; exported for operator-level parity tests).
  * -------------------------------------------------------------------------------------------- */
 /* generic GEMM C = op(A) op(B) (+ epilogue); layout 0 NT (A MxK, B NxK), 1 NN (A MxK, B KxN), 2 TN (A KxM, B KxN).

@@ -62,7 +62,10 @@ def test_size_queries_and_validation_without_gpu(amd):
     assert lib.dgvit_got_workspace_floats(ctypes.byref(bad), 4, 1) < 0
     assert lib.dgvit_linear_backward_scratch_floats(512, 128, 256) > 0
     assert lib.dgvit_gemm_scratch_floats(2, 1536, 256, 25600) >= 1536 * 256
-    assert lib.dgvit_gemm_scratch_floats(0, 1536, 256, 25600) == 0
+    # forward form: scratch only when the shape takes the in-launch split-K path (few tiles / nearly empty last round)
+    assert lib.dgvit_gemm_scratch_floats(0, 25600, 2048, 256) == 0           # 6400 tiles = 25.00 per CU: no split
+    assert lib.dgvit_gemm_scratch_floats(0, 2080, 64, 2048) >= 33 * 64 * 64  # 33 tiles of 64 x 64, K = 2048: split
+    assert lib.dgvit_gemm_scratch_floats(0, 25600, 256, 2048) >= 64 * 4 * 64 * 64   # 1600 tiles: the last 64 are cut in 4
 
 
 def test_no_cpu_fallback(amd):

@@ -156,14 +156,17 @@ class _InjectedNoise:
 
     def __enter__(self):
         from torch.distributions import Normal
-        self.orig = Normal.rsample
+        from dgvit_amd import sac_networks
+        self.orig, self.orig_draw = Normal.rsample, sac_networks._standard_normal
         eps = self.eps
         Normal.rsample = lambda self_, sample_shape=torch.Size(): self_.loc + self_.scale * eps.to(self_.loc.device)
+        sac_networks._standard_normal = lambda like: eps.to(like.device)     # the fused sample kernel's draw
         return self
 
     def __exit__(self, *a):
         from torch.distributions import Normal
-        Normal.rsample = self.orig
+        from dgvit_amd import sac_networks
+        Normal.rsample, sac_networks._standard_normal = self.orig, self.orig_draw
 
 
 @pytest.mark.parametrize("name", ["policy_native_shipped", "policy_native_small", "policy_c2"])
@@ -605,3 +608,147 @@ def test_gemm_in_launch_split_k(amd, layout, epi, M, N, K):
     assert (y1.double().cpu() - ref).abs().max().item() <= tol
     assert (y0.double().cpu() - ref).abs().max().item() <= tol
     assert (y1 - y0).abs().max().item() <= 1e-5 * K ** 0.5 * max(1.0, float(ref.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------ fused MLP heads
+def _ref_head(xs, towers):
+    x = torch.cat(xs, dim=1)
+    out = []
+    for (w1, b1, w2, b2, l3) in towers:
+        h = torch.relu(torch.relu(x @ w1.T + b1) @ w2.T + b2)
+        out.append([h @ w3.T + b3 for (w3, b3) in l3])
+    return out
+
+
+@pytest.mark.parametrize("B,ks,n1,n2,n3,towers,heads3", [
+    (1, (64,), 128, 128, 2, 1, 2),          # shipped policy head, single frame
+    (32, (64,), 128, 128, 2, 1, 2),         # shipped policy head, training batch
+    (33, (64, 2), 128, 32, 2, 2, 1),        # GoTQNetwork(l_f_size 64): cat(feat, a) -> twin towers; 2 row blocks, K0 = 66 (unaligned)
+    (512, (256,), 128, 128, 2, 1, 2),       # C3 actor head
+    (70, (256, 32, 2), 128, 32, 2, 2, 1),   # CNN QNetwork: cat(conv feat, goal embedding, action), K0 = 290
+    (5, (256, 32), 128, 32, 2, 1, 2),       # CNN GaussianPolicy
+    (40, (64,), 128, 32, 2, 1, 1),          # DeterministicGoTPolicy
+    (3, (20, 12, 1), 32, 64, 4, 2, 2),      # odd widths everywhere
+])
+def test_fused_mlp_head_forward_backward(amd, B, ks, n1, n2, n3, towers, heads3):
+    """dgvit_mlp_head_forward / _backward against fp64 PyTorch arithmetic: outputs, input gradients (per concatenated piece) and
+    every parameter gradient, for every head shape of the reference's networks."""
+    from dgvit_amd import functional as F
+    g = torch.Generator().manual_seed(B + sum(ks) + n2)
+    K0 = sum(ks)
+    xs = [torch.randn(B, k, generator=g) for k in ks]
+    tw = []
+    for _ in range(towers):
+        w1, b1 = torch.randn(n1, K0, generator=g) / K0 ** 0.5, torch.randn(n1, generator=g) * 0.1
+        w2, b2 = torch.randn(n2, n1, generator=g) / n1 ** 0.5, torch.randn(n2, generator=g) * 0.1
+        l3 = [(torch.randn(n3, n2, generator=g) / n2 ** 0.5, torch.randn(n3, generator=g) * 0.1) for _ in range(heads3)]
+        tw.append((w1, b1, w2, b2, l3))
+    dy = torch.randn(towers, heads3, B, n3, generator=g)
+    # reference in fp64
+    rx = [x.double().requires_grad_(True) for x in xs]
+    rt = [(w1.double().requires_grad_(True), b1.double().requires_grad_(True), w2.double().requires_grad_(True), b2.double().requires_grad_(True),
+           [(w3.double().requires_grad_(True), b3.double().requires_grad_(True)) for w3, b3 in l3]) for w1, b1, w2, b2, l3 in tw]
+    ry = _ref_head(rx, rt)
+    sum((ry[t][j] * dy[t, j].double()).sum() for t in range(towers) for j in range(heads3)).backward()
+    # HIP
+    def lin(w, b):
+        m = torch.nn.Linear(w.shape[1], w.shape[0])
+        m.weight.data.copy_(w); m.bias.data.copy_(b)
+        return m.cuda()
+    mods = [(lin(w1, b1), lin(w2, b2), [lin(w3, b3) for w3, b3 in l3]) for w1, b1, w2, b2, l3 in tw]
+    hx = [x.cuda().requires_grad_(True) for x in xs]
+    assert F.mlp_head_supported(hx, mods)
+    y = F.mlp_head(hx, mods)
+    assert len(y) == towers and all(len(r) == heads3 and r[0].shape == (B, n3) for r in y)
+    sum((y[t][j] * dy[t, j].cuda()).sum() for t in range(towers) for j in range(heads3)).backward()
+    for t in range(towers):
+        for j in range(heads3):
+            np.testing.assert_allclose(y[t][j].detach().cpu().numpy(), ry[t][j].detach().numpy(), rtol=0, atol=2e-5)
+    scale = max(1.0, B ** 0.5)
+    for a, b in zip(hx, rx):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=0, atol=5e-5)
+    for t in range(towers):
+        l1, l2, l3s = mods[t]
+        r = rt[t]
+        for ours, ref in ((l1.weight, r[0]), (l1.bias, r[1]), (l2.weight, r[2]), (l2.bias, r[3])):
+            np.testing.assert_allclose(ours.grad.cpu().numpy(), ref.grad.numpy(), rtol=0, atol=5e-5 * scale)
+        for j in range(heads3):
+            np.testing.assert_allclose(l3s[j].weight.grad.cpu().numpy(), r[4][j][0].grad.numpy(), rtol=0, atol=5e-5 * scale)
+            np.testing.assert_allclose(l3s[j].bias.grad.cpu().numpy(), r[4][j][1].grad.numpy(), rtol=0, atol=5e-5 * scale)
+
+
+def test_fused_mlp_head_frozen_inputs_and_canaries(amd):
+    """Raw C-ABI call with guard zones around h1, h2, y, the input gradients, the parameter gradients and the scratch; NULL slots
+    (frozen parameters / inputs without gradient) are skipped."""
+    from dgvit_amd import _lib
+    lib = _lib.load()
+    B, ks, n1, n2, n3, towers, heads3 = 45, (64, 2), 128, 32, 2, 2, 1
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(B, k, generator=g).cuda() for k in ks]
+    K0 = sum(ks)
+    shapes = [(n1, K0), (n1,), (n2, n1), (n2,), (n3, n2), (n3,)] * towers
+    params = [torch.randn(*s, generator=g).cuda() * 0.1 for s in shapes]
+    d = _lib.dgvit_mlp_desc()
+    d.batch, d.nseg, d.n1, d.n2, d.n3, d.towers, d.heads3 = B, len(ks), n1, n2, n3, towers, heads3
+    for i, x in enumerate(xs):
+        d.kx[i], d.ldx[i] = x.shape[1], x.stride(0)
+    tab = lambda ts: (ctypes.c_void_p * len(ts))(*[0 if t is None else t.data_ptr() for t in ts])
+    h1, h2, y = Guarded(towers * B * n1), Guarded(towers * B * n2), Guarded(towers * heads3 * B * n3)
+    _lib.check(lib.dgvit_mlp_head_forward(ctypes.byref(d), tab(xs), tab(params), _p(h1.t), _p(h2.t), _p(y.t), _st()), "fwd")
+    torch.cuda.synchronize()
+    for gd, what in ((h1, "h1"), (h2, "h2"), (y, "y")):
+        gd.check(what)
+        assert torch.isfinite(gd.t).all()
+    nsc = lib.dgvit_mlp_head_backward_scratch_floats(ctypes.byref(d))
+    sc = Guarded(nsc)
+    dins = [Guarded(B * ks[0]), None]                     # no gradient for the action piece
+    dpars = [Guarded(p.numel()) for p in params]
+    dpars[0] = None                                       # tower 0's first weight frozen
+    dpars[7] = None                                       # tower 1's first bias frozen
+    dy = [torch.randn(B, n3, generator=g).cuda() for _ in range(towers * heads3)]
+    rc = lib.dgvit_mlp_head_backward(ctypes.byref(d), tab(xs), tab(params), _p(h1.t), _p(h2.t), tab(dy), tab([None if q is None else q.t for q in dins]),
+                                     tab([None if q is None else q.t for q in dpars]), _p(sc.t), nsc, _st())
+    _lib.check(rc, "bwd")
+    torch.cuda.synchronize()
+    sc.check("scratch")
+    for q in dins + dpars:
+        if q is not None:
+            q.check("gradient")
+            assert torch.isfinite(q.t).all()
+
+
+@pytest.mark.parametrize("B,A,scalar", [(1, 2, True), (37, 2, True), (300, 3, False)])
+def test_fused_tanh_gaussian_sample(amd, B, A, scalar):
+    """dgvit_tanh_gaussian_forward / _backward against the reference's own op sequence (got_sac_network.py:238-251) in fp64
+    autograd, including log_std values outside the clamp range and per-action scale / bias."""
+    from dgvit_amd import functional as F
+    g = torch.Generator().manual_seed(B)
+    mean, raw, eps = torch.randn(B, A, generator=g), torch.randn(B, A, generator=g) * 3 - 1, torch.randn(B, A, generator=g)
+    raw[0, 0], raw[-1, -1] = 5.0, -30.0
+    scale = torch.tensor(1.0) if scalar else torch.rand(A, generator=g) + 0.5
+    bias = torch.tensor(0.0) if scalar else torch.randn(A, generator=g)
+    w = [torch.randn(B, A, generator=g), torch.randn(B, 1, generator=g), torch.randn(B, A, generator=g)]
+    m, r = mean.double().requires_grad_(True), raw.double().requires_grad_(True)
+    ls = torch.clamp(r, min=-20, max=2)
+    normal = torch.distributions.Normal(m, ls.exp())
+    x_t = m + ls.exp() * eps.double()
+    y_t = torch.tanh(x_t)
+    act = y_t * scale.double() + bias.double()
+    lp = (normal.log_prob(x_t) - torch.log(scale.double() * (1 - y_t.pow(2)) + 1e-6)).sum(1, keepdim=True)
+    tm = torch.tanh(m) * scale.double() + bias.double()
+    (act * w[0].double() + tm * w[2].double()).sum().add((lp * w[1].double()).sum()).backward()
+    hm, hr = mean.cuda().requires_grad_(True), raw.cuda().requires_grad_(True)
+    a2, lp2, tm2 = F.tanh_gaussian_sample(hm, hr, eps.cuda(), scale.cuda(), bias.cuda(), -20, 2)
+    ((a2 * w[0].cuda()).sum() + (lp2 * w[1].cuda()).sum() + (tm2 * w[2].cuda()).sum()).backward()
+    np.testing.assert_allclose(a2.detach().cpu().numpy(), act.detach().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(tm2.detach().cpu().numpy(), tm.detach().numpy(), rtol=0, atol=2e-6)
+    # where tanh saturates, 1 - y^2 is a few fp32 ulps against the 1e-6 epsilon (ill-conditioned in the reference's own fp32
+    # arithmetic, got_sac_network.py:248): strict comparison on rows with every |y| < 0.999, a loose bound on the others
+    ok = (y_t.detach().abs() < 0.999).all(dim=1).numpy()
+    assert ok.sum() >= B // 2
+    np.testing.assert_allclose(lp2.detach().cpu().numpy()[ok], lp.detach().numpy()[ok], rtol=1e-5, atol=2e-4)
+    np.testing.assert_allclose(lp2.detach().cpu().numpy()[~ok], lp.detach().numpy()[~ok], rtol=0.05, atol=0.5)
+    np.testing.assert_allclose(hm.grad.cpu().numpy()[ok], m.grad.numpy()[ok], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(hr.grad.cpu().numpy()[ok], r.grad.numpy()[ok], rtol=1e-4, atol=1e-4)
+    assert bool(torch.isfinite(hm.grad).all()) and bool(torch.isfinite(hr.grad).all())
+    assert hr.grad[0, 0].item() == 0.0 and hr.grad[-1, -1].item() == 0.0      # clamped entries pass no gradient
