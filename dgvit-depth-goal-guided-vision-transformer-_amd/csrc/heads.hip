@@ -41,6 +41,11 @@ struct HeadArgs {
 
 __device__ __forceinline__ int arow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// A single workgroup walks the whole head, so every global round trip that is not overlapped is pure latency: the weight
+// fragments of LB consecutive 8-deep k-groups are requested together (LB or 4 * LB loads in flight per lane) before the MFMAs
+// that consume them.
+constexpr int LB = 8;
+
 // acc(32x32) += A B with A rows in an LDS image (k contiguous, stride sa) and B[k][j = lane] = W[(jb + li) * ldw + k]
 // (weight rows straight from global / L2; k beyond kmax and rows beyond nmax read as 0)
 template <bool VEC>
@@ -48,22 +53,31 @@ __device__ __forceinline__ void mm_rows_x_wrows(f32x16& acc, const float* a_img,
                                                 int nmax, int kmax, int KP, int li, int h) {
   const bool jok = jn < nmax;
   const float* wrow = W + (long long)(jok ? jn : 0) * ldw;
-  for (int g = 0; g < KP / 8; ++g) {
-    const int k = 8 * g + 4 * h;
-    const float4 a = *reinterpret_cast<const float4*>(a_img + li * sa + k);
-    float4 b;
-    if (VEC) {
-      b = (jok && k < kmax) ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    } else {
-      b.x = (jok && k + 0 < kmax) ? wrow[k + 0] : 0.f;
-      b.y = (jok && k + 1 < kmax) ? wrow[k + 1] : 0.f;
-      b.z = (jok && k + 2 < kmax) ? wrow[k + 2] : 0.f;
-      b.w = (jok && k + 3 < kmax) ? wrow[k + 3] : 0.f;
+  const int ng = KP / 8;
+  for (int g0 = 0; g0 < ng; g0 += LB) {
+    float4 b[LB];
+#pragma unroll
+    for (int u = 0; u < LB; ++u) {
+      const int k = 8 * (g0 + u) + 4 * h;
+      if (VEC) {
+        b[u] = (jok && g0 + u < ng && k < kmax) ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        b[u].x = (jok && g0 + u < ng && k + 0 < kmax) ? wrow[k + 0] : 0.f;
+        b[u].y = (jok && g0 + u < ng && k + 1 < kmax) ? wrow[k + 1] : 0.f;
+        b[u].z = (jok && g0 + u < ng && k + 2 < kmax) ? wrow[k + 2] : 0.f;
+        b[u].w = (jok && g0 + u < ng && k + 3 < kmax) ? wrow[k + 3] : 0.f;
+      }
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < LB; ++u) {
+      if (g0 + u < ng) {
+        const float4 a = *reinterpret_cast<const float4*>(a_img + li * sa + 8 * (g0 + u) + 4 * h);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[u].w, acc, 0, 0, 0);
+      }
+    }
   }
 }
 
@@ -72,16 +86,26 @@ __device__ __forceinline__ void mm_rows_x_wrows(f32x16& acc, const float* a_img,
 __device__ __forceinline__ void mm_rows_x_wcols(f32x16& acc, const float* a_img, int sa, const float* __restrict__ W, int ldw, int jn,
                                                 int jmax, int kmax, int li, int h) {
   const bool jok = jn < jmax;
-  for (int g = 0; g < (kmax + 7) / 8; ++g) {
-    const int k = 8 * g + 4 * h;
-    const float4 a = *reinterpret_cast<const float4*>(a_img + li * sa + k);
-    float b[4];
+  const int ng = (kmax + 7) / 8;
+  for (int g0 = 0; g0 < ng; g0 += LB) {
+    float b[LB][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) b[s] = (jok && k + s < kmax) ? W[(long long)(k + s) * ldw + jn] : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3], acc, 0, 0, 0);
+    for (int u = 0; u < LB; ++u)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k = 8 * (g0 + u) + 4 * h + s;
+        b[u][s] = (jok && k < kmax) ? W[(long long)k * ldw + jn] : 0.f;
+      }
+#pragma unroll
+    for (int u = 0; u < LB; ++u) {
+      if (g0 + u < ng) {
+        const float4 a = *reinterpret_cast<const float4*>(a_img + li * sa + 8 * (g0 + u) + 4 * h);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[u][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[u][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[u][2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[u][3], acc, 0, 0, 0);
+      }
+    }
   }
 }
 
@@ -104,16 +128,19 @@ __device__ __forceinline__ void zero16(f32x16& a) {
 // concatenated input rows [row0, row0 + 32) -> LDS image [32][KP + 4], zero beyond B and beyond K0
 __device__ __forceinline__ void stage_x(const HeadArgs& a, float* xs, int row0, int tid) {
   const int SX = a.KP + 4;
-  for (int f = tid; f < HR * a.KP; f += 256) {
-    const int r = f / a.KP, k = f % a.KP;
-    float v = 0.f;
-    if (row0 + r < a.B && k < a.K0) {
-      int kk = k, sg = 0;
-      while (sg + 1 < a.nseg && kk >= a.kx[sg]) { kk -= a.kx[sg]; ++sg; }
-      v = a.x[sg][(long long)(row0 + r) * a.ldx[sg] + kk];
+  int koff = 0;
+  for (int sg = 0; sg < a.nseg; ++sg) {
+    const int kx = a.kx[sg], ld = a.ldx[sg];
+    const float* __restrict__ src = a.x[sg];
+#pragma unroll 4
+    for (int f = tid; f < HR * kx; f += 256) {
+      const int r = f / kx, k = f - r * kx;
+      xs[r * SX + koff + k] = row0 + r < a.B ? src[(long long)(row0 + r) * ld + k] : 0.f;
     }
-    xs[r * SX + k] = v;
+    koff += kx;
   }
+  const int pad = a.KP - a.K0;
+  for (int f = tid; f < HR * pad; f += 256) xs[(f / pad) * SX + a.K0 + f % pad] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -170,7 +197,11 @@ __global__ void __launch_bounds__(256) mlp_head_fwd_kernel(const HeadArgs a) {
     if (row0 + row >= a.B) continue;
     const float* w = a.w3[t][j] + (long long)o * a.n2;
     float s = a.b3[t][j][o];
-    for (int k = 0; k < a.n2; ++k) s = fmaf(h2s[row * S2 + k], w[k], s);
+#pragma unroll 8
+    for (int k = 0; k < a.n2; k += 4) {   // n2 % 32 == 0; W3 rows are 16-byte aligned when W3 is
+      const float4 wv = *reinterpret_cast<const float4*>(w + k), hv = *reinterpret_cast<const float4*>(h2s + row * S2 + k);
+      s = fmaf(hv.x, wv.x, fmaf(hv.y, wv.y, fmaf(hv.z, wv.z, fmaf(hv.w, wv.w, s))));
+    }
     a.y[(((long long)t * a.heads3 + j) * a.B + row0 + row) * a.n3 + o] = s;
   }
 }
@@ -214,10 +245,12 @@ __global__ void __launch_bounds__(256) mlp_head_bwd_kernel(const HeadArgs a) {
   float* o_b2 = a.direct ? a.db2[t] : part + po.b2;
 
   stage_x(a, xs, row0, tid);
+#pragma unroll 4
   for (int f = tid; f < HR * a.n1; f += 256) {
     const int r = f / a.n1, c = f % a.n1;
     h1s[r * S1 + c] = row0 + r < a.B ? a.h1[((long long)t * a.B + row0 + r) * a.n1 + c] : 0.f;
   }
+#pragma unroll 4
   for (int f = tid; f < HR * a.n2; f += 256) {
     const int r = f / a.n2, c = f % a.n2;
     h2s[r * S2 + c] = row0 + r < a.B ? a.h2[((long long)t * a.B + row0 + r) * a.n2 + c] : 0.f;
@@ -357,7 +390,10 @@ int fill_args(HeadArgs& a, const dgvit_mlp_desc* d, const float* const* in, cons
     for (int i = 0; i < per; ++i) DGVIT_CHECK_ARG(p[i], "mlp_head: parameter %d of tower %d is null", i, t);
     a.w1[t] = p[0]; a.b1[t] = p[1]; a.w2[t] = p[2]; a.b2[t] = p[3];
     DGVIT_CHECK_ARG((reinterpret_cast<uintptr_t>(p[2]) & 15) == 0, "mlp_head: layer-2 weight of tower %d must be 16-byte aligned", t);
-    for (int j = 0; j < d->heads3; ++j) { a.w3[t][j] = p[4 + 2 * j]; a.b3[t][j] = p[5 + 2 * j]; }
+    for (int j = 0; j < d->heads3; ++j) {
+      a.w3[t][j] = p[4 + 2 * j]; a.b3[t][j] = p[5 + 2 * j];
+      DGVIT_CHECK_ARG((reinterpret_cast<uintptr_t>(p[4 + 2 * j]) & 15) == 0, "mlp_head: third-layer weight %d of tower %d must be 16-byte aligned", j, t);
+    }
   }
   return DGVIT_OK;
 }
