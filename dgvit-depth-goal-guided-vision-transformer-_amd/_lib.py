@@ -58,6 +58,7 @@ SIGNATURES = {
     "dgvit_set_wgrad_overlap": (None, [_I]),
     "dgvit_set_grouped_reduce": (None, [_I]),
     "dgvit_set_gemm_split": (None, [_I]),
+    "dgvit_set_small_batch_path": (None, [_I, _I]),
     "dgvit_layernorm_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dgvit_layernorm_backward_scratch_floats": (_LL, [_I, _I]),
     "dgvit_layernorm_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _P]),
@@ -93,6 +94,7 @@ SIGNATURES = {
     "dgvit_cast_f32_bf16": (_I, [_P, _P, _LL, _P]),
     "dgvit_gemm_bf16": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     "dgvit_set_gemm_bf16_tile": (None, [_I]),
+    "dgvit_set_gemm_bf16_group_m": (None, [_I]),
     "dgvit_set_gemm_bf16_mfma16": (None, [_I]),
     "dgvit_set_gemm_bf16_stamps": (None, [_P]),
     "dgvit_layernorm_forward_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),

@@ -15,8 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libdgvit_hip.so")
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "embed.hip", "conv.hip", "optim.hip", "profile.hip", "preprocess.hip", "gemm_bf16.hip",
-           "attention_bf16.hip", "misc_bf16.hip", "heads.hip", "dgvit_api.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "bf16.h"), os.path.join(INCLUDE, "dgvit_hip.h")]
+           "attention_bf16.hip", "misc_bf16.hip", "heads.hip", "frame.hip", "dgvit_api.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "bf16.h"), os.path.join(CSRC, "small_mma.h"), os.path.join(INCLUDE, "dgvit_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-fvisibility=hidden", "-I", INCLUDE]
 

@@ -32,12 +32,14 @@ struct GemmBf16Params {
   const bf16_t* aux; int ldaux; // BEPI_DGELU_BF16
   int ksplit, kchunk;           // ksplit > 1: K is cut into ksplit slices of kchunk (multiple of 32); slice z writes C + z * slab_stride
   long long slab_stride;        //             (BEPI_F32_PLAIN only; the slabs are summed by reduce_slabs)
+  int group_m;                  // row panels per walk group (0 = default); see tile_mn in gemm_bf16_ring_kernel
   int tn;                       // 1: A is (K, M) with row stride lda, B is (K, N): C = A^T B (BEPI_F32_PLAIN, 256 x 256 tile)
 };
 
 int gemm_bf16(int epi, const GemmBf16Params& p, hipStream_t st);
 extern int g_gemm_bf16_tile_hint;
 extern int g_gemm_bf16_m16;
+extern int g_gemm_bf16_group_m;
 extern long long* g_gemm_bf16_stamps;
 
 int cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t st);

@@ -11,6 +11,9 @@
 
 static int g_prune_last = 1;  // last block: only token 0 feeds the output (GoalFormer.py:167)
 static int g_overlap_wgrad = 0;  // opt-in: run weight-gradient GEMMs on a helper stream beside the data-gradient chain
+static int g_small_path = 0;     // opt-in: inference as two launches per block (frame.hip).  Measured on MI355X: slower than
+                                 // the split-K GEMM schedule at B = 1 (0.34 vs 0.20 ms per sample()) and at B = 32 (0.41 vs 0.33), so it is OFF
+static int g_small_path_max_rows = 4160;   // token rows (B * N) up to which the per-frame kernels are used
 static int g_group_reduce = 1;   // one grouped slab / partial reduction per layer (0: one launch per weight gradient, A/B knob)
 
 // ---------------------------------------------------------------------------------------------- helper stream
@@ -238,7 +241,9 @@ Ws make_ws(const Dims& d, int save) {
     // inference: one shared set of temporaries; odd layers write their output into one extra
     // residual-stream buffer placed right behind it, even layers into the shared `xout`
     w.layer_stride = 0;
-    o += l + al4(d.T * d.D);
+    long long region = l + al4(d.T * d.D);
+    if (frame_path_supports(d.B, d.N, d.D, d.H, d.dh, d.M)) region = std::max(region, al4(frame_path_scratch_floats(d.B, d.N, d.D, d.H, d.M)));
+    o += region;
   }
   w.total = o;
   return w;
@@ -260,6 +265,10 @@ extern "C" void dgvit_set_prune_last_layer(int on) { g_prune_last = on ? 1 : 0; 
 extern "C" void dgvit_set_wgrad_overlap(int on) { g_overlap_wgrad = on ? 1 : 0; }
 extern "C" void dgvit_set_grouped_reduce(int on) { g_group_reduce = on ? 1 : 0; }
 extern "C" void dgvit_set_gemm_split(int on) { g_gemm_split = on ? 1 : 0; }
+extern "C" void dgvit_set_small_batch_path(int on, int max_rows) {
+  g_small_path = on ? 1 : 0;
+  if (max_rows > 0) g_small_path_max_rows = max_rows;
+}
 
 // ---------------------------------------------------------------------------------------------- encoder
 extern "C" long long dgvit_got_workspace_floats(const dgvit_config* cfg, int batch, int save) {
@@ -357,6 +366,10 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
   }
   TRY(goal_row(goal, params[P_POS], x, d.B, d.N, d.D, st));
   if (keep < 1.f) TRY(dropout_inplace(x, d.T * d.D, seed, seed_dev, keep, st));
+
+  // inference on a handful of frames (SAC.choose_action, the no-grad passes of learn() at batch 32): two launches per block
+  if (!save && g_small_path && !d.pool_mean && d.T <= g_small_path_max_rows && frame_path_supports(d.B, d.N, d.D, d.H, d.dh, d.M))
+    return frame_path_forward(x, params, d.L, ws + w.layer0, feat, d.B, d.N, d.D, d.H, d.dh, d.M, st);
 
   for (int i = 0; i < d.L; ++i) {
     const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
@@ -1018,6 +1031,7 @@ Bsb make_bsb(const Dims& d) {
 
 extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = tile; }
 extern "C" void dgvit_set_gemm_bf16_mfma16(int on) { g_gemm_bf16_m16 = on ? 1 : 0; }
+extern "C" void dgvit_set_gemm_bf16_group_m(int rows) { g_gemm_bf16_group_m = rows > 0 ? rows : 8; }
 extern "C" void dgvit_set_gemm_bf16_stamps(long long* stamps) { g_gemm_bf16_stamps = stamps; }
 
 extern "C" long long dgvit_got_bf16_weight_elems(const dgvit_config* cfg) {

@@ -26,6 +26,7 @@
 #include "kernels.h"
 
 int g_gemm_bf16_tile_hint = 0;
+int g_gemm_bf16_group_m = 8;   // A/B knob: row panels per walk group of the persistent tile order
 int g_gemm_bf16_m16 = 1;   // the ring kernel issues v_mfma_f32_16x16x32_bf16 (default; 0 = 32x32x16: A/B knob dgvit_set_gemm_bf16_mfma16)
 long long* g_gemm_bf16_stamps = nullptr;   // diagnostic: see STAMP in gemm_bf16_ring_kernel
 
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   // panels x every column panel (a 3.5-4.7 MB weight matrix alone overflows the L2)
   const int tiles_m = (p.M + BM - 1) / BM;
   auto tile_mn = [&](int t, int& m0, int& n0) {
-    constexpr int GROUP_M = 8;
+    const int GROUP_M = p.group_m;
     const int per_group = GROUP_M * tiles_n, grp_i = t / per_group, within = t - grp_i * per_group;
     const int rows = tiles_m - grp_i * GROUP_M < GROUP_M ? tiles_m - grp_i * GROUP_M : GROUP_M;
     m0 = (grp_i * GROUP_M + within % rows) * BM;
@@ -561,10 +562,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
             } else if (EPI == BEPI_BF16) {
               __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(v, bf16x4)), rsC, coff, 0, 0);
             } else if (EPI == BEPI_GELU_BF16 || EPI == BEPI_GELU2_BF16) {
-              if (EPI == BEPI_GELU2_BF16) {
-                const unsigned xoff = ok ? ((unsigned)ml * (unsigned)p.ldc2 + coln) * 2u : DGVIT_BUF_OOB;
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(v, bf16x4)), rsX, xoff, 0, 0);
-              }
+              if (EPI == BEPI_GELU2_BF16)   // ldc2 == ldc (checked at launch): the pre-activation copy shares the tile-relative offset
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(v, bf16x4)), rsX, coff, 0, 0);
               fx4 g = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
               __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(g, bf16x4)), rsC, coff, 0, 0);
             } else {  // BEPI_DGELU_BF16
@@ -605,7 +604,9 @@ int num_cus() {
 }
 
 template <class T, int EPI, bool RING>
-int launch(const GemmBf16Params& p, hipStream_t st) {
+int launch(const GemmBf16Params& p_in, hipStream_t st) {
+  GemmBf16Params p = p_in;
+  if (p.group_m <= 0) p.group_m = g_gemm_bf16_group_m > 0 ? g_gemm_bf16_group_m : 8;
   const long long tiles = (long long)((p.M + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN);
   DGVIT_CHECK_ARG(tiles < (1ll << 30), "gemm_bf16: too many tiles");
   static bool attr_done = false;   // the kernels use more than the 64 KB default dynamic LDS limit
@@ -622,6 +623,7 @@ int launch(const GemmBf16Params& p, hipStream_t st) {
         return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit to %d bytes", LDS);
       attr_done = true;
     }
+    DGVIT_CHECK_ARG(EPI != BEPI_GELU2_BF16 || (p.ldc2 == p.ldc && p.c_rgrp == 0), "gemm_bf16: the GELU epilogue with a pre-activation copy needs ldc2 == ldc");
     const int S = p.ksplit > 1 ? p.ksplit : 1;
     DGVIT_CHECK_ARG(S == 1 || (p.kchunk > 0 && p.kchunk % 32 == 0 && (long long)(S - 1) * p.kchunk < p.K && (long long)S * p.kchunk >= p.K),
                     "gemm_bf16: bad split-K plan (%d x %d over K=%d)", S, p.kchunk, p.K);

@@ -43,3 +43,7 @@ int tanh_gaussian_forward(const float*, const float*, const float*, const float*
                           int, int, hipStream_t);
 int tanh_gaussian_backward(const float*, const float*, const float*, const float*, int, float, float, const float*, const float*,
                            const float*, float*, float*, int, int, hipStream_t);
+bool frame_path_supports(int B, int N, int D, int H, int dh, int M);
+long long frame_path_scratch_floats(int B, int N, int D, int H, int M);
+int frame_path_forward(const float* x0, const float* const* params, int L, float* scratch, float* feat, int B, int N, int D, int H, int dh,
+                       int M, hipStream_t st);

@@ -251,6 +251,30 @@ def linear(x, weight, bias=None, relu=False):
     return _Linear.apply(x, weight, bias, 1 if relu else 0)
 
 
+# ------------------------------------------------------------------------------------------------ stand-alone RMSNorm
+class _RmsNorm(torch.autograd.Function):
+    """F.normalize(x, dim=-1) * sqrt(D) * g on the last dimension (GoalFormer.py:120-122) for a stand-alone RMSNorm module."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        x2 = _dev(x, "x").reshape(-1, x.shape[-1])
+        g = _dev(g, "g")
+        y = op_rmsnorm_fwd(x2, g)
+        ctx.save_for_backward(x2, g)
+        ctx.shape = x.shape
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g = ctx.saved_tensors
+        dx, dg = op_rmsnorm_bwd(_dev(dy, "dy").reshape(x2.shape), x2, g)
+        return dx.reshape(ctx.shape), dg
+
+
+def rms_norm(x, g):
+    return _RmsNorm.apply(x, g)
+
+
 # ------------------------------------------------------------------------------------------------ fused MLP heads
 def _mlp_desc(batch, xs, n1, n2, n3, towers, heads3):
     d = _lib.dgvit_mlp_desc()

@@ -8,7 +8,8 @@ fused HIP forward/backward (functional.got_encoder); none of them runs PyTorch m
 Differences from the reference, on purpose:
   * ``patch_size`` is honoured (the reference hard-wires 16x20 / Linear(320, dim), GoalFormer.py:137-139);
     with patch_size=(16, 20) the parameter shapes are identical;
-  * transformer ``dropout`` must be 0 (the only value the reference's nets ever use); ``pool`` 'cls' and 'mean' both work.
+  * transformer ``dropout`` must be 0 (the only value the reference's nets ever use); ``pool`` 'cls' and 'mean' both work;
+  * ``RMSNorm`` also works stand-alone (``unit_offset`` included).
 """
 import math
 
@@ -29,13 +30,20 @@ class _Holder(nn.Module):
         raise RuntimeError(f"{type(self).__name__} holds parameters for the fused DGViT HIP encoder and is not callable")
 
 
-class RMSNorm(_Holder):
+class RMSNorm(nn.Module):
+    """GoalFormer.py:107-122.  Inside ``GoT`` it is a parameter holder (the fused encoder applies it to the pooled token); called
+    on its own it runs the HIP RMSNorm kernels, ``unit_offset`` included (gain stored as g, applied as g + 1, init g = 0)."""
+
     def __init__(self, dim, unit_offset=False):
         super().__init__()
-        if unit_offset:
-            raise NotImplementedError("unit_offset=True is never used by the reference (GoalFormer.py:111)")
+        self.unit_offset = unit_offset
         self.scale = dim ** 0.5
-        self.g = nn.Parameter(torch.ones(dim))
+        self.g = nn.Parameter(torch.zeros(dim))
+        nn.init.constant_(self.g, 1. - float(unit_offset))
+
+    def forward(self, x):
+        gain = self.g + float(self.unit_offset) if self.unit_offset else self.g
+        return F_.rms_norm(x, gain)
 
 
 class Patchify(_Holder):

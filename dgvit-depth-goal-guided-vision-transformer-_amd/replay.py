@@ -43,25 +43,53 @@ class DeviceReplayBuffer:
     def get_stored_size(self) -> int:
         return self.stored
 
-    def add(self, **kw) -> None:
-        """One transition (numpy arrays / scalars / tensors), same keywords as replay_buffer.add in DRL.py:439-448."""
-        i = self.next_index
-        for k, n in self.fields.items():
+    def _host_rows(self, kw, n):
+        """(n, row) fp32 host matrix holding the fields of n transitions side by side (offsets in self._off)."""
+        if not hasattr(self, "_off"):
+            self._off, o = {}, 0
+            for k, r in self.rows.items():
+                self._off[k] = o
+                o += r
+            self._row = o
+        host = np.zeros((n, self._row), dtype=np.float32)
+        for k, cnt in self.fields.items():
             if k not in kw:
                 raise KeyError(f"missing field {k}")
-            v = torch.as_tensor(np.asarray(kw[k], dtype=np.float32) if not torch.is_tensor(kw[k]) else kw[k], dtype=torch.float32)
-            v = v.reshape(-1)
-            if v.numel() != n:
-                raise ValueError(f"{k}: expected {n} values, got {v.numel()}")
-            self.store[k][i, :n].copy_(v, non_blocking=True)
-        self.next_index = (i + 1) % self.size
-        self.stored = min(self.stored + 1, self.size)
+            v = kw[k].detach().cpu().numpy() if torch.is_tensor(kw[k]) else np.asarray(kw[k], dtype=np.float32)
+            v = np.asarray(v, dtype=np.float32).reshape(n, -1)
+            if v.shape[1] != cnt:
+                raise ValueError(f"{k}: expected {cnt} values per transition, got {v.shape[1]}")
+            host[:, self._off[k]:self._off[k] + cnt] = v
+        return host
+
+    def _store_rows(self, host) -> None:
+        """ONE host->device copy of the assembled rows (pinned staging), then device-side copies into the field matrices
+        (ring wrap = two slices).  The reference converts and copies every field of every sampled batch instead (DRL.py:379-386)."""
+        n = host.shape[0]
+        if n > self.size:
+            host, n = host[-self.size:], self.size
+        stage = torch.from_numpy(host).pin_memory()
+        dev = stage.to(self.device, non_blocking=True)
+        i = self.next_index
+        first = min(n, self.size - i)
+        for k, cnt in self.fields.items():
+            o = self._off[k]
+            self.store[k][i:i + first, :cnt].copy_(dev[:first, o:o + cnt])
+            if first < n:
+                self.store[k][:n - first, :cnt].copy_(dev[first:, o:o + cnt])
+        self._last_stage = (stage, dev)          # keep the pinned buffer alive until the async copy has certainly been issued
+        self.next_index = (i + n) % self.size
+        self.stored = min(self.stored + n, self.size)
+
+    def add(self, **kw) -> None:
+        """One transition (numpy arrays / scalars / tensors), same keywords as replay_buffer.add in DRL.py:439-448:
+        one staged host->device copy for the whole transition."""
+        self._store_rows(self._host_rows(kw, 1))
 
     def add_batch(self, **kw) -> None:
-        """Many transitions at once (first axis = transitions), e.g. the expert demonstrations of DRL.py:469-478."""
-        n = len(kw["obs"])
-        for j in range(n):
-            self.add(**{k: kw[k][j] for k in self.fields})
+        """Many transitions at once (first axis = transitions), e.g. the expert demonstrations of DRL.py:469-478: assembled on
+        the host with numpy slicing, one host->device copy."""
+        self._store_rows(self._host_rows(kw, len(kw["obs"])))
 
     def sample_indices(self, batch_size: int) -> torch.Tensor:
         if self.stored == 0:

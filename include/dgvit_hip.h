@@ -179,6 +179,12 @@ void dgvit_set_grouped_reduce(int on);
  * nearly empty last round of tiles, are split over K inside the launch (partial tiles + last-arriver epilogue, deterministic).
  * 0 = one workgroup per output tile.  Results agree to fp32 rounding (the order of the k-sum changes). */
 void dgvit_set_gemm_split(int on);
+/* Opt-in experiment (default OFF): dgvit_got_forward with save_for_backward == 0 and at most max_rows token rows (default
+ * 4160 = 64 frames of 65 tokens) runs every transformer block as TWO launches (one workgroup per frame and head; one per
+ * frame and 128-wide hidden chunk) instead of seven GEMM / LayerNorm / attention launches -- aimed at SAC.choose_action
+ * (DRL.py:170-185).  Correct (parity-tested) but measured slower than the split-K GEMM schedule on MI355X: each workgroup
+ * walks five dependent phases of L2 round trips, see DESIGN.md 3.7. */
+void dgvit_set_small_batch_path(int on, int max_rows);
 
 /* nn.LayerNorm(D), eps 1e-5 (GoalFormer.py:34,37): y, and the per-row mean / rstd saved for backward */
 int dgvit_layernorm_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
@@ -312,6 +318,8 @@ int dgvit_gemm_bf16(int epilogue, const unsigned short* A, int lda, const unsign
                     const unsigned short* aux, int ldaux, void* stream);
 /* test/bench knob: force the bf16 GEMM workgroup tile (0 = automatic; 256256, 256128, 128128) */
 void dgvit_set_gemm_bf16_tile(int tile);
+/* test/bench knob: row panels per walk group of the persistent bf16 GEMM's tile order (default 8) */
+void dgvit_set_gemm_bf16_group_m(int rows);
 /* A/B knob: which MFMA the ring GEMM issues: 1 (default) v_mfma_f32_16x16x32_bf16, 0 v_mfma_f32_32x32x16_bf16 (same cycles per
  * FLOP; the kernel runs under the chip's power limit and the 16x16 shape measured 2-3 % faster; same results up to summation order) */
 void dgvit_set_gemm_bf16_mfma16(int on);

@@ -752,3 +752,116 @@ def test_fused_tanh_gaussian_sample(amd, B, A, scalar):
     np.testing.assert_allclose(hr.grad.cpu().numpy()[ok], r.grad.numpy()[ok], rtol=1e-4, atol=1e-4)
     assert bool(torch.isfinite(hm.grad).all()) and bool(torch.isfinite(hr.grad).all())
     assert hr.grad[0, 0].item() == 0.0 and hr.grad[-1, -1].item() == 0.0      # clamped entries pass no gradient
+
+
+def test_replay_add_batch_is_one_staged_copy_and_wraps(amd):
+    """DeviceReplayBuffer.add_batch (expert demonstrations, DRL.py:469-478) assembles all transitions on the host and moves them
+    with one host->device copy; contents, ring wrap and the n > size case must match per-transition adds."""
+    from dgvit_amd.replay import DeviceReplayBuffer
+    rs = np.random.RandomState(1)
+    n = 21
+    demo = dict(obs=rs.rand(n, 12, 10).astype(np.float32), pobs=rs.rand(n, 2), act=rs.rand(n, 2), rew=np.arange(n, dtype=np.float32),
+                next_obs=rs.rand(n, 12, 10).astype(np.float32), next_pobs=rs.rand(n, 2), done=(np.arange(n) % 2).astype(np.float32))
+    a, b = DeviceReplayBuffer(16, obs_shape=(12, 10), seed=0), DeviceReplayBuffer(16, obs_shape=(12, 10), seed=0)
+    for j in range(5):                                   # both start 5 transitions into the ring
+        for rb in (a, b):
+            rb.add(**{k: v[j] for k, v in demo.items()})
+    a.add_batch(**{k: v[5:] for k, v in demo.items()})   # 16 more: wraps
+    for j in range(5, n):
+        b.add(**{k: v[j] for k, v in demo.items()})
+    assert a.get_stored_size() == b.get_stored_size() == 16 and a.next_index == b.next_index
+    for k in a.store:
+        assert torch.equal(a.store[k], b.store[k]), k
+    c = DeviceReplayBuffer(8, obs_shape=(12, 10))
+    c.add_batch(**demo)                                  # more transitions than slots: the last 8 survive
+    assert c.get_stored_size() == 8
+    got = c.sample(8, indices=torch.arange(8))
+    assert sorted(got["rew"].reshape(-1).tolist()) == list(range(n - 8, n))
+
+
+@pytest.mark.parametrize("unit_offset", [False, True])
+def test_standalone_rmsnorm_with_unit_offset(amd, unit_offset):
+    """RMSNorm(dim, unit_offset) of GoalFormer.py:107-122 called on its own (round 1 refused unit_offset=True)."""
+    from dgvit_amd.goalformer import RMSNorm
+    m = RMSNorm(96, unit_offset=unit_offset).cuda()
+    assert float(m.g.detach().abs().max()) == (0.0 if unit_offset else 1.0)
+    with torch.no_grad():
+        m.g.add_(torch.randn(96, device="cuda") * 0.1)
+    x = torch.randn(5, 7, 96, device="cuda", requires_grad=True)
+    y = m(x)
+    xr, gr = x.detach().double().cpu().requires_grad_(True), m.g.detach().double().cpu().requires_grad_(True)
+    ref = torch.nn.functional.normalize(xr, dim=-1) * 96 ** 0.5 * (gr + float(unit_offset))
+    w = torch.randn(5, 7, 96)
+    (y * w.cuda()).sum().backward(); (ref * w.double()).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=1e-5)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(m.g.grad.cpu().numpy(), gr.grad.numpy(), rtol=0, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ small-batch (per-frame) forward
+def _small_path(lib, on):
+    lib.dgvit_set_small_batch_path(1 if on else 0, 0)
+
+
+@pytest.mark.parametrize("name,cls", [("policy_native_shipped", "policy"), ("policy_native_small", "policy"), ("policy_c2", "policy"),
+                                      ("detpolicy_native_shipped", "det")])
+def test_small_batch_path_matches_reference_goldens(amd, name, cls):
+    """no_grad forward (what SAC.choose_action runs, DRL.py:170-185) on the opt-in two-launches-per-block path: outputs must
+    equal the reference's own (fixtures from the unmodified reference classes at 128x160) within 1e-4."""
+    fx = load_fixture(name)
+    cfg = fixture_cfg(fx)
+    batch, seed = int(fx["meta/batch"]), int(fx["meta/seed"])
+    kw = dict(image_size=cfg.image, patch_size=cfg.patch)
+    if cls == "policy":
+        m = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, **kw), O.make_params(O.policy_param_spec(cfg), seed)).eval().to("cuda")
+    else:
+        m = _load_state(amd.DeterministicGoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, **kw), O.make_params(O.detpolicy_param_spec(cfg), seed)).eval().to("cuda")
+    img, pstate, _, _ = O.make_inputs(cfg, batch, seed)
+    lib = amd.load_library()
+    _small_path(lib, True)
+    try:
+        with torch.no_grad():
+            out = m([img.cuda(), pstate.cuda()])
+    finally:
+        _small_path(lib, False)
+    if cls == "policy":
+        np.testing.assert_allclose(out[0].cpu().numpy(), fx["mean"], rtol=0, atol=OUT_TOL)
+        np.testing.assert_allclose(out[1].cpu().numpy(), fx["log_std"], rtol=0, atol=OUT_TOL)
+    else:
+        np.testing.assert_allclose(out.cpu().numpy(), fx["mean"], rtol=0, atol=OUT_TOL)
+
+
+@pytest.mark.parametrize("image,patch,dim,depth,heads,dim_head,B", [
+    ((128, 160), (16, 20), 64, 4, 4, 64, 1), ((128, 160), (16, 20), 64, 4, 4, 64, 2), ((128, 160), (16, 20), 64, 4, 4, 64, 32),
+    ((84, 84), (12, 12), 256, 2, 8, 64, 3),      # DGViT-small width, N = 50
+    ((84, 84), (14, 14), 96, 2, 3, 32, 5),       # N = 37, dim_head 32, odd widths
+    ((84, 84), (7, 7), 64, 1, 2, 64, 2),         # N = 145 > 128: not eligible, must fall through to the large-batch schedule
+    ((24, 24), (24, 24), 32, 2, 1, 64, 4),       # N = 2
+])
+def test_small_batch_path_equals_large_batch_schedule(amd, image, patch, dim, depth, heads, dim_head, B):
+    """Same module, same inputs, eval and train mode (same dropout seed): the per-frame kernels and the GEMM schedule must agree
+    to fp32 summation-order rounding, and both with the oracle."""
+    lib = amd.load_library()
+    cfg = O.GoTConfig(image=image, patch=patch, dim=dim, depth=depth, heads=heads, dim_head=dim_head, mlp_dim=256 if dim < 64 else 2048)
+    params = O.make_params(O.got_param_spec(cfg, prefix=""), 17)
+    m = amd.GoT(image_size=image, patch_size=patch, num_classes=2, dim=dim, depth=depth, heads=heads, mlp_dim=cfg.mlp_dim, channels=1, dim_head=dim_head)
+    m.load_state_dict(params, strict=True)
+    m = m.cuda()
+    img, _, _, _ = O.make_inputs(cfg, B, 17)
+    goal = torch.randn(B, dim, generator=torch.Generator().manual_seed(3))
+    ref = O.got_forward(params, img, goal, cfg, prefix="") if hasattr(O, "got_forward") else None
+    outs = {}
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        for on in (True, False):
+            _small_path(lib, on)
+            try:
+                torch.manual_seed(5)      # same dropout seed draw for both paths
+                with torch.no_grad():
+                    outs[(mode, on)] = m(img.cuda(), goal.cuda()).cpu()
+            finally:
+                _small_path(lib, False)      # the library's default
+        np.testing.assert_allclose(outs[(mode, True)].numpy(), outs[(mode, False)].numpy(), rtol=0, atol=5e-5)
+    if ref is not None:
+        np.testing.assert_allclose(outs[("eval", True)].numpy(), ref.detach().numpy(), rtol=0, atol=OUT_TOL)
+    assert (outs[("train", True)] - outs[("eval", True)]).abs().max().item() > 1e-3      # dropout was live in train mode

@@ -46,7 +46,7 @@ def main():
     rows.sort()
     ends = [i for i, r in enumerate(rows) if marker in r[2]]
     # a step ends at the LAST adam launch of a cluster of adam launches (encoder run, heads run: a few dispatches apart)
-    step_ends = [i for j, i in enumerate(ends) if j + 1 == len(ends) or ends[j + 1] - i > 20]
+    step_ends = [i for j, i in enumerate(ends) if j + 1 == len(ends) or ends[j + 1] - i > 6]
     hi = step_ends[-back]
     lo = step_ends[-back - 1] + 1
     step = rows[lo:hi + 1]
