@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--profile-stride", type=int, default=10, help="time every n-th launch of each kernel kind with HIP events (1 = every launch)")
     ap.add_argument("--no-overlap-ab", action="store_true", help="skip the forward-only pass and the helper-stream A/B after the timed region (use when profiling: they launch the same kernels)")
     ap.add_argument("--no-c5", action="store_true", help="skip the secondary config-5 (224x224 ViT-Base, bf16) forward measurement")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the secondary launch-bound measurements (single-frame sample(), shipped learn() step)")
     ap.add_argument("--wgrad-overlap", action="store_true", help="A/B: weight-gradient GEMMs on the helper stream (+5%% frames/s, blurs per-kernel timing)")
     ap.add_argument("--dense-last-block", action="store_true", help="A/B: compute the last block for every token")
     ap.add_argument("--force-collective", action="store_true",
@@ -125,6 +126,60 @@ def sac_step(dgvit_amd, synthetic, B, dev, steps=5):
     dt = (time.perf_counter() - t0) / steps
     return {"ms_per_step": round(dt * 1e3, 3), "frames_per_s": round(B / dt, 1), "encoder_passes": "5 fwd + 3 bwd per frame",
             "note": "transformer actor + transformer critic, DRL.py:390-432 arithmetic"}
+
+
+def small_batch(dgvit_amd, synthetic, dev):
+    """Secondary numbers in the reference's own regime (BASELINE config 1 / SURVEY 7 hard part 8): one 128x160 frame through the
+    shipped actor's sample() (SAC.choose_action, DRL.py:170-185), and one SAC learn() step of the shipped configuration
+    (config.yaml: GoT actor L4/H4/D64 + CNN critic, batch 32; DRL.py:373-437), each replayed as ONE captured HIP graph."""
+    import copy
+    from dgvit_amd.optim import FlatAdam, soft_update
+    torch.manual_seed(3407)
+    pol = dgvit_amd.GoTPolicy(2, 2, 4, 4, 64).to(dev)
+    img1, ps1, _, _ = (t.to(dev) for t in synthetic.make_inputs((128, 160), 1, 0))
+
+    def one_frame():
+        with torch.no_grad():
+            return pol.sample([img1, ps1])
+
+    def timed(fn, n):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    eager = timed(one_frame, 100)
+    graph = timed(dgvit_amd.GraphedStep(one_frame, warmup=3), 300)
+    B = 32
+    crt = dgvit_amd.QNetwork(2, 2).to(dev)
+    tgt = copy.deepcopy(crt)
+    op, oc = FlatAdam([pol], lr=1e-3, capturable=True), FlatAdam([crt], lr=1e-3, capturable=True)
+    img, ps, act, _ = (t.to(dev) for t in synthetic.make_inputs((128, 160), B, 1))
+    nimg, nps, _, _ = (t.to(dev) for t in synthetic.make_inputs((128, 160), B, 2))
+    rew = torch.randn(B, 1, device=dev)
+
+    def learn():
+        with torch.no_grad():
+            na, nlogp, _ = pol.sample([nimg, nps])
+            q1n, q2n = tgt([nimg, nps, na])
+            y = rew + 0.99 * (torch.min(q1n, q2n) - 0.2 * nlogp)
+        q1, q2 = crt([img, ps, act])
+        qf = torch.nn.functional.mse_loss(q1, y) + torch.nn.functional.mse_loss(q2, y)
+        oc.zero_grad(); qf.backward(); oc.step()
+        pi, logp, _ = pol.sample([img, ps])
+        q1p, q2p = crt([img, ps, pi])
+        pl = (0.2 * logp - torch.min(q1p, q2p)).mean()
+        op.zero_grad(); oc.zero_grad(); pl.backward(); op.step()
+        soft_update(tgt, crt, 0.005)
+    learn_eager = timed(learn, 20)
+    learn_graph = timed(dgvit_amd.GraphedStep(learn, warmup=2), 50)
+    return {"single_frame_sample_ms": {"eager": round(eager * 1e3, 4), "hip_graph": round(graph * 1e3, 4)},
+            "shipped_learn_step_ms": {"eager": round(learn_eager * 1e3, 3), "hip_graph": round(learn_graph * 1e3, 3), "batch": B},
+            "note": "shipped configuration of the reference (config.yaml:5,11,58-63): GoT actor L4/H4/D64 on 128x160 frames, CNN critic; "
+                    "round 1: 0.41 ms per graphed sample(), 3.66 ms per graphed learn() step"}
 
 
 def c5_bf16(dgvit_amd, lib, _lib, dev, batch=440, steps=10):
@@ -339,24 +394,28 @@ def main():
 
         traffic = None
         try:   # HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (tools/pmc_traffic.py)
-            with open(os.path.join(ROOT, "profiles", "r01_m_hbm_traffic.json")) as f:
+            tpath = os.path.join(ROOT, "profiles", "r02_a_hbm_traffic.json")
+            if not os.path.exists(tpath):
+                tpath = os.path.join(ROOT, "profiles", "r01_m_hbm_traffic.json")
+            with open(tpath) as f:
                 traffic = json.load(f)["kernels"]["gemm_f32_kernel"]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
-            pass
+            tpath = None
         out = {
             "metric": "depth frames/sec through DGViT fwd+bwd, batch 512x84x84",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C3: GoTPolicy DGViT-small (84x84@12x12, L6 H8 D256 M2048, N=50 tokens) actor fwd+bwd, "
-                                   "train mode (emb dropout 0.1), MSE-to-random-target loss, grad all-reduce + Adam step (fused flat-buffer HIP Adam)",
+                                   "train mode (emb dropout 0.1), MSE-to-random-target loss, grad all-reduce + Adam step (fused flat-buffer HIP Adam)"
+                                   + (" [one-rank RCCL group, all-reduce forced]" if args.force_collective else ""),
                        "frames_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "gflop_per_frame_fwd_bwd": round(3 * fwd / 1e9, 4),
                        "last_block": "dense" if args.dense_last_block else "token-0 rows only (identical results; FLOPs counted dense)",
                        "wgrad_overlap": bool(args.wgrad_overlap)},
             "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes (profiles/r01_m_hbm_traffic.json)",
+                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes (" + (os.path.relpath(tpath, ROOT) if tpath else "not collected") + ")",
                          "kernel": "gemm_f32_kernel (all instantiations: NT fwd, NN dgrad, TN wgrad)",
                          "launches_per_step": int(cnt_all[0] // max(1, args.steps)),
                          "avg_launch_ms": round(ms[0] / max(1, cnt[0]), 5),
@@ -379,6 +438,8 @@ def main():
             out["wgrad_overlap_ab"] = overlap_ab
         if world == 1 and not args.no_sac_step:
             out["sac_step"] = sac_step(dgvit_amd, synthetic, B, dev)
+        if world == 1 and not args.no_small_batch:
+            out["small_batch"] = small_batch(dgvit_amd, synthetic, dev)
         if world == 1 and not args.no_c5:
             out["c5_bf16"] = c5_bf16(dgvit_amd, lib, _lib, dev)
         if world == 1 and not args.no_cpu_baseline:

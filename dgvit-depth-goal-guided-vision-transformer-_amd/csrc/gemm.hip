@@ -321,12 +321,17 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
     typename FB::Plan pb;
     FA::plan(pa, p.A, p.lda, m0, p.M, kbeg, p.K, tid);
     FB::plan(pb, p.B, p.ldb, n0, p.N, kbeg, p.K, tid);
-    FA::run4(ra, pa, 0, klim);
-    FB::run4(rb, pb, 0, klim);
-    FA::stash(ra, smem, tid);
-    FB::stash(rb, smem + A_TILE, tid);
-    FA::run4(ra, pa, 1, klim);
-    FB::run4(rb, pb, 1, klim);
+    // prologue: the fetches of k-tiles 0 AND 1 are in flight together (one exposed round trip per output tile instead of two;
+    // with K = 256 a tile has only 8-16 k-tiles to amortise it over)
+    {
+      float4 ra0[FA::NV], rb0[FB::NV];
+      FA::run4(ra0, pa, 0, klim);
+      FB::run4(rb0, pb, 0, klim);
+      FA::run4(ra, pa, 1, klim);
+      FB::run4(rb, pb, 1, klim);
+      FA::stash(ra0, smem, tid);
+      FB::stash(rb0, smem + A_TILE, tid);
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       const float* la = smem + (kt & 1) * STAGE;
