@@ -44,7 +44,12 @@ struct GemmParams {
   int lda, ldb;
   int M, N, K;
   int kchunk;            // K range handled by one blockIdx.z (multiple of BK); == K when not split
-  int a_kgrp;            // must be 0 (row gathers are done by the caller)
+  int a_kgrp;            // must be 0
+  // patch gather of the A operand (NT, patch embedding; GoalFormer.py:138 'b (h p1) (w p2) -> b (h w) (p1 p2)' folded into the
+  // tile loader): g_img != null => A[m][k] = img[b][hy * ph + p1][wx * pw + p2] with m = b * P + hy * gw + wx, k = p1 * pw + p2;
+  // `A` / `lda` are ignored.  Needs pw % 4 == 0, image width % 4 == 0 and a 16-byte aligned image (float4 loads never cross a patch row).
+  const float* g_img; long long g_img_floats;
+  int g_wi, g_hw, g_ph, g_pw, g_gw, g_P, g_inv;   // image width, image height * width, patch h / w, patches per row / frame, 65536 / pw + 1
   float* C; int ldc;
   const float* bias;     // [N] or null
   const float* res; int ldr;  // residual [*][N] or null

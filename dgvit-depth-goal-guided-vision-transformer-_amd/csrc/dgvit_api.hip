@@ -265,6 +265,7 @@ extern "C" void dgvit_set_prune_last_layer(int on) { g_prune_last = on ? 1 : 0; 
 extern "C" void dgvit_set_wgrad_overlap(int on) { g_overlap_wgrad = on ? 1 : 0; }
 extern "C" void dgvit_set_grouped_reduce(int on) { g_group_reduce = on ? 1 : 0; }
 extern "C" void dgvit_set_gemm_split(int on) { g_gemm_split = on ? 1 : 0; }
+extern "C" void dgvit_set_gemm_lds_pad(int bytes) { g_gemm_lds_pad = bytes > 0 ? bytes : 0; }
 extern "C" void dgvit_set_small_batch_path(int on, int max_rows) {
   g_small_path = on ? 1 : 0;
   if (max_rows > 0) g_small_path_max_rows = max_rows;
@@ -355,12 +356,23 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
   // patch embedding (GoalFormer.py:137-139,157) + goal token, positional embedding, dropout (:160-163)
   float* patches = ws + w.patches;
   float* x = ws + w.x0;
-  TRY(patchify(img, patches, d.B, cfg->image_h, cfg->image_w, cfg->patch_h, cfg->patch_w, st));
+  // Inference: the patch rearrangement (GoalFormer.py:138) happens inside the GEMM's A-tile loader -- depth patches go from the
+  // image straight into the LDS tiles, no (B * P, pd) copy in HBM.  Training keeps the copy: the weight gradient reads it.
+  const int inv = 65536 / cfg->patch_w + 1;
+  bool gather = !save && cfg->patch_w % 4 == 0 && cfg->image_w % 4 == 0 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)params[P_PW] & 15) == 0 &&
+                (long long)d.pd * inv < (1ll << 31) && (long long)d.B * cfg->image_h * cfg->image_w < (1ll << 29);
+  for (int k = 0; gather && k < d.pd; ++k) gather = (int)(((unsigned)k * (unsigned)inv) >> 16) == k / cfg->patch_w;   // exact k / pw
+  if (!gather) TRY(patchify(img, patches, d.B, cfg->image_h, cfg->image_w, cfg->patch_h, cfg->patch_w, st));
   {
     GemmParams p = gp(patches, d.pd, params[P_PW], d.pd, x, d.D, d.B * d.P, d.D, d.pd);
     p.bias = params[P_PB];
     p.res = params[P_POS]; p.ldr = d.D; p.res_mod = d.P;  // + pos_embedding[1 + patch]
     p.c_rgrp = d.P;                                       // row (b, patch) -> token row b*N + 1 + patch
+    if (gather) {
+      p.g_img = img; p.g_img_floats = (long long)d.B * cfg->image_h * cfg->image_w;
+      p.g_wi = cfg->image_w; p.g_hw = cfg->image_h * cfg->image_w; p.g_ph = cfg->patch_h; p.g_pw = cfg->patch_w;
+      p.g_gw = cfg->image_w / cfg->patch_w; p.g_P = d.P; p.g_inv = inv;
+    }
     sk.attach(p);
     TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
   }

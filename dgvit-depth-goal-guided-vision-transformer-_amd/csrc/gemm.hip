@@ -33,6 +33,7 @@
   } while (0)
 
 extern int g_gemm_split;
+extern int g_gemm_lds_pad;
 
 namespace {
 
@@ -60,8 +61,9 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define DGVIT_OOB 0xFFFFFFF0u
 
-template <int R, int BK, bool KC, int VEC, int NT>
+template <int R, int BK, bool KC, int VEC, int NT, bool GATHER = false>
 struct Fetch {
+  static_assert(!GATHER || (KC && VEC == 4), "the patch gather is a k-contiguous float4 fetch");
   static_assert(R * BK / 4 % NT == 0, "tile must split evenly over the workgroup's threads");
   static constexpr int NV = R * BK / 4 / NT;  // float4 slots per thread
   static constexpr int PER_ROW = KC ? BK / 4 : R / 4;
@@ -73,7 +75,29 @@ struct Fetch {
     int kc[NV];         // KC: k offset of the slot inside a tile; MC: k row of the slot inside a tile
     unsigned bad[NV];   // MC: all ones when the slot's columns lie outside the matrix (OR-ed into the offset: no branch), else 0
     unsigned kstep;     // bytes to advance per k-tile
+    int g_wi, g_pw, g_inv;   // GATHER: image width, patch width, 65536 / pw + 1
   };
+
+  // GATHER: A is never materialised.  Row m of the patch matrix starts at pixel (b, hy * ph, wx * pw) of the image; element k of
+  // the row is p1 = k / pw image rows further down and p2 = k % pw pixels to the right (k / pw by multiply-shift, exact for the
+  // k < 65536 / pw that dgvit_api checks).  The descriptor covers the whole image buffer.
+  __device__ static __forceinline__ void plan_gather(Plan& pl, const GemmParams& p, int r0, int tid) {
+    long long bytes = p.g_img_floats * 4;
+    if (bytes > 0x7FFFFFFFll) bytes = 0x7FFFFFFFll;
+    pl.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g_img), 0, (int)bytes, 0x00020000);
+    pl.kstep = 0;
+    pl.g_wi = p.g_wi; pl.g_pw = p.g_pw; pl.g_inv = p.g_inv;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * NT;
+      const int a = f / PER_ROW, c = (f % PER_ROW) * 4;
+      const int m = r0 + a;
+      const int b = m / p.g_P, pi = m - b * p.g_P, hy = pi / p.g_gw, wx = pi - hy * p.g_gw;
+      pl.off[i] = ((unsigned)b * (unsigned)p.g_hw + (unsigned)(hy * p.g_ph) * (unsigned)p.g_wi + (unsigned)(wx * p.g_pw)) * 4u;
+      pl.kc[i] = c;
+      pl.bad[i] = m < p.M ? 0u : 0xFFFFFFFFu;
+    }
+  }
 
   __device__ static __forceinline__ void plan(Plan& pl, const float* base, int ld, int r0, int rmax, int kbeg, int ktotal,
                                               int tid) {
@@ -111,7 +135,13 @@ struct Fetch {
   __device__ static __forceinline__ void run4(float4 (&reg)[NV], const Plan& pl, int t, int klim) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const unsigned at = (pl.off[i] + (unsigned)t * pl.kstep) | pl.bad[i];   // num_records <= 0x7FFFFFFF: all ones is out of range
+      unsigned at;
+      if constexpr (GATHER) {
+        const unsigned k = (unsigned)(t * BK + pl.kc[i]), p1 = (k * (unsigned)pl.g_inv) >> 16, p2 = k - p1 * (unsigned)pl.g_pw;
+        at = (pl.off[i] + (p1 * (unsigned)pl.g_wi + p2) * 4u) | pl.bad[i];
+      } else {
+        at = (pl.off[i] + (unsigned)t * pl.kstep) | pl.bad[i];   // num_records <= 0x7FFFFFFF: all ones is out of range
+      }
       const unsigned o = t * BK + pl.kc[i] < klim ? at : DGVIT_OOB;
       reg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(pl.rsrc, o, 0, 0));
     }
@@ -228,7 +258,7 @@ __device__ __forceinline__ void sched_pattern() {
 }
 #undef SGB
 
-template <class T, int LAYOUT, int VEC, int EPI>
+template <class T, int LAYOUT, int VEC, int EPI, bool GATHER = false>
 __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NT;
   constexpr bool AKC = LAYOUT != GEMM_TN;
@@ -238,7 +268,7 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
   constexpr int A_TILE = AKC ? BM * (BK + 4) : BK * (BM + 4);
   constexpr int B_TILE = BKC ? BN * (BK + 4) : BK * (BN + 4);
   constexpr int STAGE = A_TILE + B_TILE;
-  using FA = Fetch<BM, BK, AKC, VEC, NT>;
+  using FA = Fetch<BM, BK, AKC, VEC, NT, GATHER>;
   using FB = Fetch<BN, BK, BKC, VEC, NT>;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -319,7 +349,8 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
     // the fetch is branch-free (hardware range check), so loads, LDS writes and MFMAs share one basic block.
     typename FA::Plan pa;
     typename FB::Plan pb;
-    FA::plan(pa, p.A, p.lda, m0, p.M, kbeg, p.K, tid);
+    if constexpr (GATHER) FA::plan_gather(pa, p, m0, tid);
+    else FA::plan(pa, p.A, p.lda, m0, p.M, kbeg, p.K, tid);
     FB::plan(pb, p.B, p.ldb, n0, p.N, kbeg, p.K, tid);
     // prologue: the fetches of k-tiles 0 AND 1 are in flight together (one exposed round trip per output tile instead of two;
     // with K = 256 a tile has only 8-16 k-tiles to amortise it over)
@@ -499,12 +530,18 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), srs, (unsigned)(((ch * CROWS + rr) * BN + cc) * 4), 0, 16);
       }
     } else if (n < p.N) {
-      for (int rr = rr0; rr < CROWS; rr += RPP) {
+      // CROWS / RPP row pieces per thread, four at a time: the LDS reads (and the side inputs `finish` loads) of a group are
+      // in flight together instead of one dependent round trip per piece
+      static_assert(CROWS % RPP == 0, "epilogue row pieces");
+#pragma unroll 4
+      for (int it = 0; it < CROWS / RPP; ++it) {
+        const int rr = rr0 + it * RPP;
         const int m = m0 + ch * CROWS + rr;
-        if (m >= p.M) break;
-        const float4 t = *reinterpret_cast<const float4*>(smem + rr * CS + cc);
-        float v[4] = {t.x, t.y, t.z, t.w};
-        finish(m, v);
+        if (m < p.M) {
+          const float4 t = *reinterpret_cast<const float4*>(smem + rr * CS + cc);
+          float v[4] = {t.x, t.y, t.z, t.w};
+          finish(m, v);
+        }
       }
     }
     if (ch + 1 < NCHUNK) __syncthreads();
@@ -646,7 +683,7 @@ inline GemmSplitPlan split_plan(int M, int N, int K, int BM, int BN, int BK, int
   return pl;
 }
 
-template <class T, int LAYOUT, int VEC, int EPI>
+template <class T, int LAYOUT, int VEC, int EPI, bool GATHER = false>
 int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK;
   constexpr bool AKC = LAYOUT != GEMM_TN;
@@ -655,9 +692,9 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
   constexpr int B_TILE = BKC ? BN * (BK + 4) : BK * (BN + 4);
   constexpr size_t lds = 2 * (A_TILE + B_TILE) * sizeof(float);
   static bool attr_done = false;
-  auto kern = gemm_f32_kernel<T, LAYOUT, VEC, EPI>;
+  auto kern = gemm_f32_kernel<T, LAYOUT, VEC, EPI, GATHER>;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return dgvit_set_error(DGVIT_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_done = true;
   }
@@ -667,7 +704,7 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
   long long blocks = tiles;
   p.nsplit = 1;
   p.split_from = (int)tiles;
-  if (EPI != EPI_SPLITK && VEC == 4 && p.counters && p.slabs && p.evec && g_gemm_split) {
+  if (EPI != EPI_SPLITK && VEC == 4 && !GATHER && p.counters && p.slabs && p.evec && g_gemm_split) {
     const int occ = (int)std::min<size_t>(8, (160 * 1024) / lds);
     const GemmSplitPlan pl = split_plan(p.M, p.N, p.K, BM, BN, BK, occ);
     if (pl.nsplit > 1 && pl.slab_floats <= p.slab_capacity && tiles <= p.counter_capacity) {
@@ -677,14 +714,14 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
   }
   dim3 grid((unsigned)blocks, 1, (unsigned)nsplit);
   const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, stream);
-  hipLaunchKernelGGL(kern, grid, dim3(T::NT), lds, stream, p);
+  hipLaunchKernelGGL(kern, grid, dim3(T::NT), lds + (size_t)g_gemm_lds_pad, stream, p);
   profile_end(slot, stream);
   DGVIT_CHECK_LAUNCH("gemm_f32_kernel");
   return DGVIT_OK;
 }
 
 // tile_hint = BM*1000000 + BN*1000 + BK (e.g. 128128032), 0 = automatic
-#define DGVIT_TILES(X) X(128, 128, 32) X(128, 128, 16) X(64, 64, 32) X(64, 64, 64) X(128, 64, 32) X(64, 128, 32) X(128, 64, 16) X(64, 128, 16)
+#define DGVIT_TILES(X) X(128, 128, 32) X(128, 128, 16) X(64, 64, 32) X(64, 64, 64) X(128, 64, 32) X(64, 128, 32) X(128, 64, 16) X(64, 128, 16) X(64, 64, 16)
 
 // measured on MI355X at T = 25600 token rows (tools/gemm_shapes_bench.py, profiles/r01_b_gemm_tiles.txt):
 // weight gradients (long K, split over tokens) like the 128x128 tile; forward / data-gradient GEMMs are
@@ -696,6 +733,9 @@ inline int auto_tile(int layout, int M, int N) {
 
 template <int LAYOUT, int EPI>
 int pick_tile(const GemmParams& p, int nsplit, bool vec4, int tile_hint, hipStream_t stream) {
+  if constexpr (LAYOUT == GEMM_NT && EPI == EPI_STORE) {
+    if (p.g_img) return launch<TileCfg<64, 64, 32>, LAYOUT, 4, EPI, true>(p, nsplit, stream);   // patch gather in the A loader
+  }
   if (!vec4) return launch<TileCfg<64, 64, 32>, LAYOUT, 1, EPI>(p, nsplit, stream);
   int choice = tile_hint;
   if (choice == 64) choice = 64064032;
@@ -713,6 +753,7 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 }  // namespace
 
 int g_gemm_tile_hint = 0;  // test/bench override: 0 auto, 64, 128
+int g_gemm_lds_pad = 0;    // diagnostic: extra dynamic LDS bytes per workgroup (caps the workgroups per CU: occupancy probe)
 int g_gemm_split = 1;      // A/B knob: in-launch split-K of the forward / data-gradient GEMMs
 
 GemmSplitPlan gemm_split_plan(int layout, int M, int N, int K) {
@@ -727,7 +768,10 @@ GemmSplitPlan gemm_split_plan(int layout, int M, int N, int K) {
 }
 
 int gemm_f32(int layout, int epi, const GemmParams& p, int nsplit, hipStream_t stream) {
-  DGVIT_CHECK_ARG(p.A && p.B && p.C, "gemm: null operand");
+  DGVIT_CHECK_ARG((p.A || p.g_img) && p.B && p.C, "gemm: null operand");
+  DGVIT_CHECK_ARG(!p.g_img || (layout == GEMM_NT && epi == EPI_STORE && p.g_pw % 4 == 0 && p.g_wi % 4 == 0 && al16(p.g_img) && al16(p.B) &&
+                               p.ldb % 4 == 0 && p.K % 4 == 0 && p.K == p.g_ph * p.g_pw && (long long)p.K * p.g_inv < (1ll << 31)),
+                  "gemm: patch gather needs the NT / store form, patch and image widths that are multiples of 4 and 16-byte aligned operands");
   DGVIT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
   DGVIT_CHECK_ARG(nsplit >= 1 && p.kchunk > 0 && p.kchunk % 32 == 0, "gemm: kchunk must be a positive multiple of 32");
   DGVIT_CHECK_ARG((long long)p.kchunk * nsplit >= p.K, "gemm: split does not cover K");

@@ -35,6 +35,7 @@ int gaussian_blur_band(const float*, float*, float*, int, int, int, int, int, in
 int resize_bilinear(const float*, float*, int, int, int, int, int, float, hipStream_t);
 extern int g_gemm_tile_hint;
 extern int g_gemm_split;
+extern int g_gemm_lds_pad;
 int mlp_head_forward(const dgvit_mlp_desc*, const float* const*, const float* const*, float*, float*, float*, hipStream_t);
 long long mlp_head_backward_scratch(const dgvit_mlp_desc*);
 int mlp_head_backward(const dgvit_mlp_desc*, const float* const*, const float* const*, const float*, const float*, const float* const*,

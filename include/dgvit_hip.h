@@ -179,6 +179,8 @@ void dgvit_set_grouped_reduce(int on);
  * nearly empty last round of tiles, are split over K inside the launch (partial tiles + last-arriver epilogue, deterministic).
  * 0 = one workgroup per output tile.  Results agree to fp32 rounding (the order of the k-sum changes). */
 void dgvit_set_gemm_split(int on);
+/* diagnostic: request `bytes` more dynamic LDS per fp32 GEMM workgroup than it uses (caps the workgroups per CU: occupancy probes) */
+void dgvit_set_gemm_lds_pad(int bytes);
 /* Opt-in experiment (default OFF): dgvit_got_forward with save_for_backward == 0 and at most max_rows token rows (default
  * 4160 = 64 frames of 65 tokens) runs every transformer block as TWO launches (one workgroup per frame and head; one per
  * frame and 128-wide hidden chunk) instead of seven GEMM / LayerNorm / attention launches -- aimed at SAC.choose_action

@@ -865,3 +865,34 @@ def test_small_batch_path_equals_large_batch_schedule(amd, image, patch, dim, de
     if ref is not None:
         np.testing.assert_allclose(outs[("eval", True)].numpy(), ref.detach().numpy(), rtol=0, atol=OUT_TOL)
     assert (outs[("train", True)] - outs[("eval", True)]).abs().max().item() > 1e-3      # dropout was live in train mode
+
+
+@pytest.mark.parametrize("image,patch", [((84, 84), (12, 12)), ((128, 160), (16, 20)), ((224, 224), (16, 16)), ((36, 60), (12, 12)),
+                                          ((84, 84), (14, 14)), ((84, 84), (7, 7))])
+def test_patch_gather_in_the_gemm_loader(amd, image, patch):
+    """Inference forwards take the depth patches straight from the image in the patch-embedding GEMM's tile loader
+    (GoalFormer.py:138 folded into the loader; eligible when patch and image widths are multiples of 4); training forwards keep
+    the materialised patch matrix.  Same weights, same frames: both must give the same features (and match the oracle)."""
+    cfg = O.GoTConfig(image=image, patch=patch, dim=64, depth=1, heads=2)
+    params = O.make_params(O.got_param_spec(cfg, prefix=""), 23)
+    m = amd.GoT(image_size=image, patch_size=patch, num_classes=2, dim=64, depth=1, heads=2, mlp_dim=cfg.mlp_dim, channels=1)
+    m.load_state_dict(params, strict=True)
+    m = m.cuda().eval()
+    B = 70 if image == (36, 60) else 5                    # 70 frames x 15 patches: several row tiles, a ragged last one
+    img, _, _, _ = O.make_inputs(cfg, B, 23)
+    goal = torch.randn(B, 64, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        f_gather = m(img.cuda(), goal.cuda()).cpu()                          # save = 0: gather path where eligible
+    gg = goal.cuda().requires_grad_(True)
+    f_copy = m(img.cuda(), gg).detach().cpu()                                # save = 1: patchify + GEMM
+    np.testing.assert_allclose(f_gather.numpy(), f_copy.numpy(), rtol=0, atol=2e-5)
+    ref = O.got_forward(params, img, goal, cfg, prefix="")
+    np.testing.assert_allclose(f_gather.numpy(), ref.detach().numpy(), rtol=0, atol=OUT_TOL)
+    # an image view that is not 16-byte aligned falls back to the copy (and still gives the same result)
+    big = torch.zeros(B * image[0] * image[1] + 1, device="cuda")
+    off = big[1:].view(B, *image)
+    off.copy_(img)
+    assert off.data_ptr() % 16 != 0
+    with torch.no_grad():
+        f_off = m(off, goal.cuda()).cpu()
+    np.testing.assert_allclose(f_off.numpy(), f_copy.numpy(), rtol=0, atol=2e-5)
