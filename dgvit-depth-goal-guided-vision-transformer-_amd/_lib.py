@@ -96,6 +96,7 @@ SIGNATURES = {
     "dgvit_gemm_bf16": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
     "dgvit_set_gemm_bf16_tile": (None, [_I]),
     "dgvit_set_gemm_bf16_group_m": (None, [_I]),
+    "dgvit_set_attention_bwd_single_pass": (None, [_I]),
     "dgvit_set_gemm_bf16_mfma16": (None, [_I]),
     "dgvit_set_gemm_bf16_stamps": (None, [_P]),
     "dgvit_layernorm_forward_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),

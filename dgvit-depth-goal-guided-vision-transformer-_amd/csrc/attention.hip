@@ -350,6 +350,193 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_bwd_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------ backward, 32 < N <= 64, all queries
+// (the DGViT-small shapes: N = 50 at 84x84 @ 12x12, N = 37 @ 14x14).  The two-phase kernel above recomputes S and dP in the second
+// orientation: 224 MFMAs per (query tile, key tile) pair.  Here every pair is computed ONCE, by its own wave (4 waves = 2 query
+// tiles x 2 key tiles):
+//   step 1 (wave = (qt, kt), K / V images in LDS, query on the lane): S^T, dP^T -> P^T, dS^T in registers; both tiles also go to
+//          LDS as [key][query] images; dQ^T partial = K^T dS^T straight from the registers.           96 MFMAs
+//   step 2 the two key-tile partials of dQ are added through LDS (fixed order) and stored.
+//   step 3 (Q / dO images written over K / V from the fragments step 1 already holds; wave = (kt, qt), key on the lane): the [key][query] images are read back as B
+//          operands (one float4 per 4 queries): dV^T += dO^T P, dK^T += Q^T dS.                           64 MFMAs
+//   step 4 the two query-tile partials of dK / dV are added through LDS and stored.
+// 160 MFMAs per pair instead of 224, no second fetch of K / V fragments, no lse / delta arrays; 70 KB of LDS (2 workgroups per CU,
+// 8 waves, as before) and a third of the per-wave dependent MFMA chain.
+template <int DH>
+__global__ void __launch_bounds__(256, 2) attn_bwd64_kernel(const float* __restrict__ qkv, const float* __restrict__ o_fwd,
+                                                            const float* __restrict__ d_out, const float* __restrict__ lse,
+                                                            float* __restrict__ dqkv, int N, int H, float scale) {
+  constexpr int SK = DH + 4, DT = DH / 32, NP = 64, TQ = NP + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* X = smem;                 // step 1: K      step 3: Q
+  float* Y = X + NP * SK;          // step 1: V      step 3: dO
+  float* TP = Y + NP * SK;         // P^T  [key][query]        (step 4: dK partial [key][d])
+  float* TS = TP + NP * TQ;        // dS^T [key][query]        (step 4: dV partial [key][d])
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x / H, hd = blockIdx.x % H;
+  const int I = H * DH;
+  const long long ld = 3ll * I;
+  const float* base = qkv + (long long)b * N * ld + hd * DH;
+  const float* obase = o_fwd + (long long)b * N * I + hd * DH;
+  const float* dobase = d_out + (long long)b * N * I + hd * DH;
+  float* gbase = dqkv + (long long)b * N * ld + hd * DH;
+  const float qscale = scale * DGVIT_LOG2E;
+  // ---- step 1: wave (qt, kt)
+  {
+    const int qt = wave & 1, kt = wave >> 1;
+    const int q = qt * 32 + li;
+    const bool qv = q < N;
+    const int qc = qv ? q : 0;
+    float4 qf[DH / 8], dof[DH / 8];
+    float delta, lq;
+    {
+      float4 of[DH / 8];
+      row_frags<DH>(qf, base + qc * ld, qv, h, qscale);
+      row_frags<DH>(dof, dobase + (long long)qc * I, qv, h, 1.f);
+      row_frags<DH>(of, obase + (long long)qc * I, qv, h, 1.f);
+      lq = qv ? lse[((long long)b * H + hd) * N + qc] : 0.f;
+      float d = 0.f;
+#pragma unroll
+      for (int g = 0; g < DH / 8; ++g) d += (dof[g].x * of[g].x + dof[g].y * of[g].y) + (dof[g].z * of[g].z + dof[g].w * of[g].w);
+      delta = d + __shfl_xor(d, 32, 64);
+    }
+    stage_pair<DH, SK, 256>(X, base + I, ld, Y, base + 2 * I, ld, N, NP, tid);
+    __syncthreads();
+    f32x16 sT, dpT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sT[r] = 0.f;
+      dpT[r] = 0.f;
+    }
+    mfma_rows_x_frags<DH, SK>(sT, X, kt * 32 + li, h, qf);      // S^T[key][query] (base-2 scaled)
+    mfma_rows_x_frags<DH, SK>(dpT, Y, kt * 32 + li, h, dof);    // dP^T[key][query]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + acc_row(r, h);
+      const float pv = key < N ? __builtin_amdgcn_exp2f(sT[r] - lq) : 0.f;
+      const float ds = pv * (dpT[r] - delta) * scale;
+      TP[key * TQ + q] = pv;         // consecutive lanes -> consecutive queries: conflict-free
+      TS[key * TQ + q] = ds;
+      sT[r] = ds;
+    }
+    f32x16 dq[DT];
+    zero_tiles<DT>(dq);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* krow = X + (kt * 32 + acc_row(r, h)) * SK + li;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[dt * 32], sT[r], dq[dt], 0, 0, 0);
+    }
+    __syncthreads();                 // every wave is done with the K / V images
+    // ---- step 2: dQ = partial(kt = 0) + partial(kt = 1), through the (now free) X image, rows = queries
+    float* ex = X + (qt * 32 + li) * SK;
+    if (kt == 1) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          *reinterpret_cast<float4*>(ex + dt * 32 + 8 * c + 4 * h) = make_float4(dq[dt][4 * c], dq[dt][4 * c + 1], dq[dt][4 * c + 2], dq[dt][4 * c + 3]);
+    }
+    __syncthreads();
+    if (kt == 0 && qv) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 o = *reinterpret_cast<const float4*>(ex + dt * 32 + 8 * c + 4 * h);
+          *reinterpret_cast<float4*>(gbase + q * ld + dt * 32 + 8 * c + 4 * h) =
+              make_float4(dq[dt][4 * c] + o.x, dq[dt][4 * c + 1] + o.y, dq[dt][4 * c + 2] + o.z, dq[dt][4 * c + 3] + o.w);
+        }
+    }
+    __syncthreads();
+    // ---- step 3 images straight from the registers: the kt = 0 waves hold every query row (q pre-scaled, undone at the store) and
+    // every dO row as fragments already; rows >= N are zero.  No second trip to global memory.
+    if (kt == 0) {
+#pragma unroll
+      for (int g = 0; g < DH / 8; ++g) {
+        *reinterpret_cast<float4*>(X + q * SK + 8 * g + 4 * h) = qf[g];
+        *reinterpret_cast<float4*>(Y + q * SK + 8 * g + 4 * h) = dof[g];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- step 3: wave (kt, qt), key on the lane
+  {
+    const int kt = wave & 1, qt = wave >> 1;
+    const int key = kt * 32 + li;
+    f32x16 dk[DT], dv[DT];
+    zero_tiles<DT>(dk);
+    zero_tiles<DT>(dv);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 pf = *reinterpret_cast<const float4*>(TP + key * TQ + qt * 32 + 8 * g + 4 * h);
+      const float4 sf = *reinterpret_cast<const float4*>(TS + key * TQ + qt * 32 + 8 * g + 4 * h);
+      const float pe[4] = {pf.x, pf.y, pf.z, pf.w}, se[4] = {sf.x, sf.y, sf.z, sf.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int q = qt * 32 + 8 * g + 4 * h + e;
+        const float* dorow = Y + q * SK + li;
+        const float* qrow = X + q * SK + li;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow[dt * 32], pe[e], dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[dt * 32], se[e], dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                 // the [key][query] images have been consumed
+    // ---- step 4: dK / dV = partial(qt = 0) + partial(qt = 1), through the TP / TS regions, rows = keys
+    float* ek = TP + key * TQ;
+    float* ev = TS + key * TQ;
+    if (qt == 1) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          *reinterpret_cast<float4*>(ek + dt * 32 + 8 * c + 4 * h) = make_float4(dk[dt][4 * c], dk[dt][4 * c + 1], dk[dt][4 * c + 2], dk[dt][4 * c + 3]);
+          *reinterpret_cast<float4*>(ev + dt * 32 + 8 * c + 4 * h) = make_float4(dv[dt][4 * c], dv[dt][4 * c + 1], dv[dt][4 * c + 2], dv[dt][4 * c + 3]);
+        }
+    }
+    __syncthreads();
+    if (qt == 0 && key < N) {
+      const float unscale = 1.f / qscale;   // the Q image holds q * scale * log2(e)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 a = *reinterpret_cast<const float4*>(ek + dt * 32 + 8 * c + 4 * h);
+          const float4 bq = *reinterpret_cast<const float4*>(ev + dt * 32 + 8 * c + 4 * h);
+          *reinterpret_cast<float4*>(gbase + I + key * ld + dt * 32 + 8 * c + 4 * h) =
+              make_float4((dk[dt][4 * c] + a.x) * unscale, (dk[dt][4 * c + 1] + a.y) * unscale, (dk[dt][4 * c + 2] + a.z) * unscale,
+                          (dk[dt][4 * c + 3] + a.w) * unscale);
+          *reinterpret_cast<float4*>(gbase + 2 * I + key * ld + dt * 32 + 8 * c + 4 * h) =
+              make_float4(dv[dt][4 * c] + bq.x, dv[dt][4 * c + 1] + bq.y, dv[dt][4 * c + 2] + bq.z, dv[dt][4 * c + 3] + bq.w);
+        }
+    }
+  }
+}
+
+int g_attn_bwd64 = 1;   // A/B knob: 0 = the two-phase kernel for every shape
+
+template <int DH>
+int launch_bwd64(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, int B, int N, int H, float scale,
+                 hipStream_t stream) {
+  constexpr size_t lds = (size_t)(2 * 64 * (DH + 4) + 2 * 64 * 68) * sizeof(float);
+  auto kern = attn_bwd64_kernel<DH>;
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return dgvit_set_error(DGVIT_ERR_HIP, "attention_bwd: %s", hipGetErrorString(e));
+    done = true;
+  }
+  const int slot = profile_begin(PROF_ATTN_BWD, 8.0 * B * H * (double)N * N * DH, stream);
+  hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), lds, stream, qkv, o, dout, lse, dqkv, N, H, scale);
+  profile_end(slot, stream);
+  DGVIT_CHECK_LAUNCH("attention_bwd64");
+  return DGVIT_OK;
+}
+
 constexpr int MAX_TOKENS = 224;
 
 template <int DH, int NW, int NKT_CT>
@@ -419,6 +606,8 @@ int attention_fwd(const float* qkv, float* out, float* lse, int B, int N, int H,
 
 // dqkv (B, N, 3*H*dh); with nq < N only rows < nq of `o`/`dout`/`lse` are read and only rows < nq of dq are written
 // (dk, dv: all rows)
+void attention_bwd_single_pass(int on) { g_attn_bwd64 = on ? 1 : 0; }
+
 int attention_bwd(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, int B, int N, int H,
                   int dh, int nq, hipStream_t stream) {
   DGVIT_CHECK_ARG(qkv && o && dout && lse && dqkv && B > 0 && N > 0 && H > 0, "attention_bwd: bad arguments");
@@ -426,6 +615,10 @@ int attention_bwd(const float* qkv, const float* o, const float* dout, const flo
   DGVIT_CHECK_ARG(nq >= 1 && nq <= N, "attention_bwd: bad query count");
   DGVIT_CHECK_ARG(N <= MAX_TOKENS && (dh == 64 || dh == 32), "attention_bwd: unsupported dim_head=%d / tokens=%d", dh, N);
   const float scale = 1.0f / sqrtf((float)dh);
+  if (g_attn_bwd64 && nq == N && N > 32 && N <= 64) {   // the DGViT-small token counts: every tile pair computed once
+    if (dh == 64) return launch_bwd64<64>(qkv, o, dout, lse, dqkv, B, N, H, scale, stream);
+    return launch_bwd64<32>(qkv, o, dout, lse, dqkv, B, N, H, scale, stream);
+  }
   ATTN_DISPATCH(launch_bwd, qkv, o, dout, lse, dqkv, B, N, H, scale, nq, stream)
   return dgvit_set_error(DGVIT_ERR_ARG, "attention_bwd: no kernel for dim_head=%d", dh);
 }

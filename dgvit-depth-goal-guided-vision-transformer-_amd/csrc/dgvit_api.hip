@@ -1043,6 +1043,7 @@ Bsb make_bsb(const Dims& d) {
 
 extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = tile; }
 extern "C" void dgvit_set_gemm_bf16_mfma16(int on) { g_gemm_bf16_m16 = on ? 1 : 0; }
+extern "C" void dgvit_set_attention_bwd_single_pass(int on) { attention_bwd_single_pass(on); }
 extern "C" void dgvit_set_gemm_bf16_group_m(int rows) { g_gemm_bf16_group_m = rows > 0 ? rows : 8; }
 extern "C" void dgvit_set_gemm_bf16_stamps(long long* stamps) { g_gemm_bf16_stamps = stamps; }
 

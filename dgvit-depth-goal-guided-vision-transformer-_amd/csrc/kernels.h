@@ -14,6 +14,7 @@ int colsum_blocks(int T);
 int colsum(const float*, long long, float*, float*, int, int, int, hipStream_t);
 int attention_fwd(const float*, float*, float*, int, int, int, int, int, hipStream_t);
 int attention_bwd(const float*, const float*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+void attention_bwd_single_pass(int on);
 int patchify(const float*, float*, int, int, int, int, int, hipStream_t);
 int goal_row(const float*, const float*, float*, int, int, int, hipStream_t);
 int dropout_inplace(float*, long long, unsigned long long, const unsigned long long*, float, hipStream_t);

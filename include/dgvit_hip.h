@@ -322,6 +322,9 @@ int dgvit_gemm_bf16(int epilogue, const unsigned short* A, int lda, const unsign
 void dgvit_set_gemm_bf16_tile(int tile);
 /* test/bench knob: row panels per walk group of the persistent bf16 GEMM's tile order (default 8) */
 void dgvit_set_gemm_bf16_group_m(int rows);
+/* A/B knob: 1 (default) the single-pass fp32 attention backward for 32 < N <= 64 (every tile pair computed once); 0 the two-phase
+ * kernel for every shape.  Same results up to summation order. */
+void dgvit_set_attention_bwd_single_pass(int on);
 /* A/B knob: which MFMA the ring GEMM issues: 1 (default) v_mfma_f32_16x16x32_bf16, 0 v_mfma_f32_32x32x16_bf16 (same cycles per
  * FLOP; the kernel runs under the chip's power limit and the 16x16 shape measured 2-3 % faster; same results up to summation order) */
 void dgvit_set_gemm_bf16_mfma16(int on);

@@ -896,3 +896,28 @@ def test_patch_gather_in_the_gemm_loader(amd, image, patch):
     with torch.no_grad():
         f_off = m(off, goal.cuda()).cpu()
     np.testing.assert_allclose(f_off.numpy(), f_copy.numpy(), rtol=0, atol=2e-5)
+
+
+# ---------------------------------------------------------------- single-pass attention backward (32 < N <= 64)
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,H,dh", [(5, 50, 8, 64), (3, 37, 2, 64), (2, 64, 4, 32), (2, 33, 1, 64)])
+def test_attention_backward_single_pass_equals_two_phase(B, N, H, dh):
+    """The single-pass kernel (every query-tile x key-tile pair computed once, P^T / dS^T crossing LDS) and the two-phase kernel
+    it replaces for these shapes are the same function: equal up to fp32 summation order."""
+    import dgvit_amd
+    from dgvit_amd import functional as F
+    lib = dgvit_amd.load_library()
+    g = torch.Generator().manual_seed(N * 7 + H)
+    qkv = torch.randn(B, N, 3 * H * dh, generator=g).cuda()
+    dout = torch.randn(B, N, H * dh, generator=g).cuda()
+    out, lse = F.op_attention_fwd(qkv, H, dh)
+    try:
+        lib.dgvit_set_attention_bwd_single_pass(0)
+        two_phase = F.op_attention_bwd(qkv, out, dout, lse, H, dh).clone()
+    finally:
+        lib.dgvit_set_attention_bwd_single_pass(1)
+    single = F.op_attention_bwd(qkv, out, dout, lse, H, dh)
+    assert torch.isfinite(single).all()
+    torch.testing.assert_close(single, two_phase, atol=2e-5, rtol=1e-5)
+    again = F.op_attention_bwd(qkv, out, dout, lse, H, dh)
+    assert torch.equal(single, again), "fixed summation order: bit-identical from run to run"
