@@ -265,6 +265,15 @@ extern "C" void dgvit_set_prune_last_layer(int on) { g_prune_last = on ? 1 : 0; 
 extern "C" void dgvit_set_wgrad_overlap(int on) { g_overlap_wgrad = on ? 1 : 0; }
 extern "C" void dgvit_set_grouped_reduce(int on) { g_group_reduce = on ? 1 : 0; }
 extern "C" void dgvit_set_gemm_split(int on) { g_gemm_split = on ? 1 : 0; }
+extern "C" void dgvit_set_gemm_stamps(long long* stamps, int workgroups) {
+  g_gemm_stamps = stamps;
+  g_gemm_stamp_capacity = stamps ? workgroups : 0;
+}
+extern "C" void dgvit_set_gemm_persistent(int mode, int workgroups) {
+  g_gemm_persist = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+  g_gemm_persist_grid = workgroups > 0 ? workgroups : 0;
+}
+extern "C" void dgvit_set_gemm_loop_priority(int on) { g_gemm_loop_prio = on ? 1 : 0; }
 extern "C" void dgvit_set_gemm_lds_pad(int bytes) { g_gemm_lds_pad = bytes > 0 ? bytes : 0; }
 extern "C" void dgvit_set_small_batch_path(int on, int max_rows) {
   g_small_path = on ? 1 : 0;

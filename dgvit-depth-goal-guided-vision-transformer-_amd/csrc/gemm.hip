@@ -34,6 +34,11 @@
 
 extern int g_gemm_split;
 extern int g_gemm_lds_pad;
+extern int g_gemm_persist;
+extern int g_gemm_persist_grid;
+extern int g_gemm_loop_prio;
+extern long long* g_gemm_stamps;
+extern int g_gemm_stamp_capacity;
 
 namespace {
 
@@ -43,6 +48,10 @@ namespace {
 template <int BM_, int BN_, int BK_, int WVM_ = 2, int WVN_ = 2>
 struct TileCfg {
   static constexpr int BM = BM_, BN = BN_, BK = BK_, WVM = WVM_, WVN = WVN_, NT = 64 * WVM_ * WVN_;
+  // workgroups per CU the two LDS stages allow (<= 32 KB each: 5, the occupancy the K = 256 shapes are tuned at); the register
+  // allocator is held to it, so an epilogue variant cannot silently cost a resident workgroup
+  static constexpr int LDS_BYTES = 2 * (BM_ + BN_) * (BK_ + 4) * 4;
+  static constexpr int MINB = LDS_BYTES * 5 <= 160 * 1024 ? 5 : 2;
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {
@@ -258,8 +267,21 @@ __device__ __forceinline__ void sched_pattern() {
 }
 #undef SGB
 
+// diagnostic stamps (dgvit_set_gemm_stamps): wave 0 of every workgroup records the shader clock at four points and where it ran
+__device__ __forceinline__ void stamp(const GemmParams& p, int slot, int tid) {
+  if (p.stamps && tid == 0 && (int)blockIdx.x < p.stamp_capacity) {
+    long long* s = p.stamps + (long long)blockIdx.x * 16;
+    s[slot] = __builtin_readcyclecounter();
+    if (slot == 0) {
+      s[4] = wall_clock64();
+      s[5] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);   // HW_ID, XCC_ID
+    }
+    if (slot == 3) s[6] = wall_clock64();
+  }
+}
+
 template <class T, int LAYOUT, int VEC, int EPI, bool GATHER = false>
-__global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) {
+__global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmParams p) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NT;
   constexpr bool AKC = LAYOUT != GEMM_TN;
   constexpr bool BKC = LAYOUT == GEMM_NT;
@@ -310,6 +332,24 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
 
   float4 ra[FA::NV], rb[FB::NV];
   const int klim = kend - kbeg;
+  stamp(p, 0, tid);
+
+  // epilogue geometry: accumulator (col = lane&31, row = (r&3) + 8*(r>>2) + 4*h) -> LDS C image [rows][BN+4] -> float4 row pieces
+  constexpr int CS = BN + 4;
+  constexpr int NCHUNK = (BM * CS <= 2 * STAGE) ? 1 : T::WVM;   // whole tile at once, or one wave-row of the tile at a time
+  constexpr int CROWS = BM / NCHUNK;
+  static_assert(CROWS * CS <= 2 * STAGE && (NCHUNK == 1 || CROWS == WM), "epilogue C image does not fit the staging LDS");
+  constexpr int C4 = BN / 4, RPP = NT / C4;
+  const int cc = (tid % C4) * 4, rr0 = tid / C4;
+  const int n = n0 + cc;
+  // The bias row piece is fetched BEFORE the main loop (4 registers): at the epilogue it would be a dependent round trip of
+  // several thousand cycles under load, paid by every tile.
+  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+  if ((EPI == EPI_STORE || EPI == EPI_GELU2 || EPI == EPI_RELU) && p.bias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (n + e < p.N) bias4[e] = p.bias[n + e];
+  }
 
   // LDS -> fragments of one 8-deep k-group; MFMAs of one k-group
   auto load_frags = [&](float (&fa)[TM][4], float (&fb)[TN][4], const float* la, const float* lb, int g) {
@@ -364,6 +404,8 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
       FB::stash(rb0, smem + A_TILE, tid);
     }
     __syncthreads();
+    stamp(p, 1, tid);
+    if (p.loop_prio) __builtin_amdgcn_s_setprio(2);   // A/B knob: main-loop waves ahead of the prologue / epilogue waves they share a SIMD with
     for (int kt = 0; kt < nk; ++kt) {
       const float* la = smem + (kt & 1) * STAGE;
       const float* lb = la + A_TILE;
@@ -388,6 +430,7 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
       }
       __syncthreads();
     }
+    if (p.loop_prio) __builtin_amdgcn_s_setprio(0);
   } else {
     FA::run(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
     FB::run(rb, p.B, p.ldb, n0, p.N, kbeg, kend, tid);
@@ -417,25 +460,12 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
     }
   }
 
+  stamp(p, 2, tid);
   // ---- epilogue ------------------------------------------------------------------------------------
   float* Cz = p.C;
   if (EPI == EPI_SPLITK) {
     Cz += (long long)blockIdx.z * p.slab_stride;
     if (p.colsum && n0 == 0 && tid < BM && m0 + tid < p.M) Cz[(long long)p.M * p.N + m0 + tid] = bsum;
-  }
-  // accumulator (col = lane&31, row = (r&3) + 8*(r>>2) + 4*h) -> LDS C image [rows][BN+4] -> float4 rows
-  constexpr int CS = BN + 4;
-  constexpr int NCHUNK = (BM * CS <= 2 * STAGE) ? 1 : T::WVM;   // whole tile at once, or one wave-row of the tile at a time
-  constexpr int CROWS = BM / NCHUNK;
-  static_assert(CROWS * CS <= 2 * STAGE && (NCHUNK == 1 || CROWS == WM), "epilogue C image does not fit the staging LDS");
-  constexpr int C4 = BN / 4, RPP = NT / C4;
-  const int cc = (tid % C4) * 4, rr0 = tid / C4;
-  const int n = n0 + cc;
-  float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-  if ((EPI == EPI_STORE || EPI == EPI_GELU2 || EPI == EPI_RELU) && p.bias) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (n + e < p.N) bias4[e] = p.bias[n + e];
   }
   // one output row piece (row m, columns n .. n+3, v = the k-complete sums): fused epilogue arithmetic and the global stores
   auto finish = [&](int m, float (&v)[4]) {
@@ -496,6 +526,39 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
   // k-slice of a split tile: the raw partial sums go to this slice's dense [BM][BN] slab
   float* slab = nullptr;
   if (EPI != EPI_SPLITK && nz > 1) slab = p.slabs + ((long long)(tile - p.split_from) * nz + zs) * (BM * BN);
+  // ---- vector fast path (p.evec: every shape of the encoder).  Stamps showed the per-piece `finish` below spending 12-18 k
+  // cycles per chunk: a conditional side-input load inside the piece loop makes the compiler wait vmcnt(0) at the merge point
+  // of every piece, and on gfx9 that also waits for the PREVIOUS piece's store - a serial chain of loaded-memory round trips
+  // (~4 k cycles each), a third of a K = 256 tile's life.  Here the side inputs (residual / activation-gradient operand) of
+  // every piece are fetched first, with row indices clamped instead of branched on, so nothing is in flight behind a store;
+  // then each chunk is LDS reads -> arithmetic -> stores back to back, no wait in between.
+  constexpr int NP = CROWS / RPP;                       // row pieces per thread and chunk
+  static_assert(CROWS % RPP == 0, "epilogue row pieces");
+  constexpr bool HAS_SIDE = EPI == EPI_STORE || EPI == EPI_DGELU || EPI == EPI_DRELU;
+  constexpr bool SIDE_ALL = NCHUNK * NP <= 4;           // all chunks' side inputs fit in 16 registers: fetch them up front
+  const bool fast = p.evec && !slab;
+  const bool nvalid = n < p.N;
+  const int nc = nvalid ? n : 0;
+  const bool use_side = HAS_SIDE && (EPI == EPI_STORE ? p.res != nullptr : true);
+  float4 side[HAS_SIDE ? (SIDE_ALL ? NCHUNK * NP : NP) : 1];
+  auto load_side = [&](int ch, float4* dst) {
+#pragma unroll
+    for (int it = 0; it < NP; ++it) {
+      const int m = min(m0 + ch * CROWS + rr0 + it * RPP, p.M - 1);
+      const float* sp;
+      if (EPI == EPI_STORE) {
+        const long long rrow = p.res_mod > 0 ? (long long)(m % p.res_mod) + 1 : (long long)m;
+        sp = p.res + rrow * p.ldr + nc;
+      } else {
+        sp = p.aux + (long long)m * p.ldaux + nc;
+      }
+      dst[it] = *reinterpret_cast<const float4*>(sp);
+    }
+  };
+  if (HAS_SIDE && SIDE_ALL && fast && use_side) {
+#pragma unroll
+    for (int ch = 0; ch < NCHUNK; ++ch) load_side(ch, side + ch * NP);
+  }
 #pragma unroll
   for (int ch = 0; ch < NCHUNK; ++ch) {
     if (NCHUNK == 1 || wm == ch) {
@@ -521,6 +584,7 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
         }
     }
     __syncthreads();
+    stamp(p, 8 + 2 * ch, tid);       // chunk's C image in LDS
     if (slab) {
       // write-through (sc1) stores: the partial tile leaves this XCD's L2 at once, so no release fence (an L2 write-back of
       // every dirty line the other workgroups' C stores left there) is needed before the ticket
@@ -529,10 +593,48 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
         const float4 t = *reinterpret_cast<const float4*>(smem + rr * CS + cc);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), srs, (unsigned)(((ch * CROWS + rr) * BN + cc) * 4), 0, 16);
       }
+    } else if (fast) {
+      if (HAS_SIDE && !SIDE_ALL && use_side) load_side(ch, side);   // big tiles: per chunk (waits for the previous chunk's stores)
+      float4* sd = side + (HAS_SIDE && SIDE_ALL ? ch * NP : 0);
+      if (EPI == EPI_DGELU) {   // operand -> gelu'(operand) in place, piece by piece (keeps the erf temporaries of one piece live)
+#pragma unroll
+        for (int it = 0; it < NP; ++it)
+          sd[it] = make_float4(gelu_erf_grad(sd[it].x), gelu_erf_grad(sd[it].y), gelu_erf_grad(sd[it].z), gelu_erf_grad(sd[it].w));
+      }
+      float4 t[NP];
+#pragma unroll
+      for (int it = 0; it < NP; ++it) t[it] = *reinterpret_cast<const float4*>(smem + (rr0 + it * RPP) * CS + cc);
+#pragma unroll
+      for (int it = 0; it < NP; ++it) {
+        const int m = m0 + ch * CROWS + rr0 + it * RPP;
+        float v[4] = {t[it].x, t[it].y, t[it].z, t[it].w}, w2[4];
+        if (EPI == EPI_STORE) {
+          if (use_side) { v[0] += sd[it].x; v[1] += sd[it].y; v[2] += sd[it].z; v[3] += sd[it].w; }   // same order as `finish`: residual, then bias
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+        } else if (EPI == EPI_GELU2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] += bias4[e];
+            w2[e] = gelu_erf(v[e]);
+          }
+        } else if (EPI == EPI_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
+        } else if (EPI == EPI_DGELU || EPI == EPI_DRELU) {
+          const float a4[4] = {sd[it].x, sd[it].y, sd[it].z, sd[it].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = EPI == EPI_DGELU ? v[e] * a4[e] : (a4[e] > 0.f ? v[e] : 0.f);
+        }
+        if (m < p.M && nvalid) {
+          long long crow = m;
+          if (EPI == EPI_STORE && p.c_rgrp > 0) crow = (long long)m + m / p.c_rgrp + 1;
+          *reinterpret_cast<float4*>(Cz + crow * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+          if (EPI == EPI_GELU2) *reinterpret_cast<float4*>(p.C2 + (long long)m * p.ldc2 + n) = make_float4(w2[0], w2[1], w2[2], w2[3]);
+        }
+      }
     } else if (n < p.N) {
-      // CROWS / RPP row pieces per thread, four at a time: the LDS reads (and the side inputs `finish` loads) of a group are
-      // in flight together instead of one dependent round trip per piece
-      static_assert(CROWS % RPP == 0, "epilogue row pieces");
+      // element-wise path (unaligned / odd-N callers): one piece at a time through `finish`
 #pragma unroll 4
       for (int it = 0; it < CROWS / RPP; ++it) {
         const int rr = rr0 + it * RPP;
@@ -544,7 +646,13 @@ __global__ void __launch_bounds__(T::NT, 2) gemm_f32_kernel(const GemmParams p) 
         }
       }
     }
+    stamp(p, 9 + 2 * ch, tid);       // chunk's stores issued
     if (ch + 1 < NCHUNK) __syncthreads();
+  }
+  stamp(p, 3, tid);                                                 // stores issued
+  if (p.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // diagnostic run only: the last stamp sees them drained
+    stamp(p, 7, tid);
   }
   if (EPI != EPI_SPLITK && nz > 1) {
     // publish the slab, take a ticket (cdna_hip_programming.md Guideline 16, recipe R1): write-through payload, every storing
@@ -647,6 +755,243 @@ __global__ void __launch_bounds__(256) reduce_slabs_scalar_kernel(const float* _
   else out2[i - n1] = s;
 }
 
+// ---- persistent variant: tile loop inside the workgroup, next tile's fetch under the epilogue ----------------------------------
+// Stamps of the per-tile kernel (tools/gemm_stamps.py, profiles/r02_c_*) at the K = 256 shapes: a workgroup spends ~15 % of its
+// life waiting for its first two k-tiles (one loaded-memory round trip, 8-15 k cycles) and ~25 % in the epilogue, and only the
+// remaining ~60 % in the main loop, where the MFMA pipe is ~94 % busy.  With 5 resident workgroups per CU that is the 0.79 pipe use
+// the counters show.  Here a workgroup walks over several tiles (grid = resident slots; tile id += gridDim.x, same XCD-contiguous
+// order), and between the main loop and the epilogue of tile t it issues the fetch of tile t+1's first two k-tiles; the epilogue
+// stores the accumulators straight from registers (buffer stores: a lane's 32-bit (NT) or 64-bit (NN) pieces, 128 / 256
+// contiguous bytes per half-wave; rows past M dropped by the descriptor's range check, columns past N by an out-of-range
+// offset), so the LDS stages are free for the next tile and no barrier separates a tile's stores from the next tile's loop.
+// Order of memory operations per tile end (vmcnt retires in order on gfx9, so nothing may wait behind a store):
+//   side-input loads (residual / activation-gradient operand), folded into the accumulators -> next tile's fetch -> stores.
+// NT and NN forms, 16-byte-aligned operands, no row remap / residual broadcast / split tiles (those stay on gemm_f32_kernel).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <class T, int LAYOUT, int EPI>
+__global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_pkernel(const GemmParams p) {
+  constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NT;
+  static_assert(LAYOUT == GEMM_NT || LAYOUT == GEMM_NN, "persistent GEMM: forward / data-gradient forms");
+  static_assert(EPI != EPI_SPLITK, "persistent GEMM: complete-K tiles");
+  constexpr bool BKC = LAYOUT == GEMM_NT;
+  constexpr int WM = BM / T::WVM, WN = BN / T::WVN, TM = WM / 32, TN = WN / 32;
+  constexpr int A_TILE = BM * (BK + 4);
+  constexpr int B_TILE = BKC ? BN * (BK + 4) : BK * (BN + 4);
+  constexpr int STAGE = A_TILE + B_TILE;
+  constexpr int CW = BKC ? 1 : TN;            // floats per store: NT one column per MFMA tile, NN the lane's TN adjacent columns
+  static_assert(CW == 1 || CW == 2, "persistent GEMM: one or two adjacent columns per lane");
+  using FA = Fetch<BM, BK, true, 4, NT>;
+  using FB = Fetch<BN, BK, BKC, 4, NT>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wm = wave / T::WVN, wn = wave % T::WVN;
+  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+  const int nk = (p.K + BK - 1) / BK, klim = p.K;
+
+  // (lane coordinates of the main loop are re-derived from an opaque copy of the thread id at every tile, see `tq` below: LDS
+  //  addresses are then computed per tile instead of living in registers across the epilogue, where the accumulators, the next
+  //  tile's fetch and the store offsets need the room)
+  int tq = tid;
+  auto load_frags = [&](float (&fa)[TM][4], float (&fb)[TN][4], const float* la, const float* lb, int g) {
+    const int li_ = tq & 31, h_ = (tq >> 5) & 1, wm_ = (tq >> 6) / T::WVN, wn_ = (tq >> 6) % T::WVN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) frag<BM, BK, true>(fa[i], la, wm_ * WM + i * 32 + li_, g, h_);
+    if constexpr (BKC) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) frag<BN, BK, true>(fb[j], lb, wn_ * WN + j * 32 + li_, g, h_);
+    } else {
+      frag_mc<BN, TN>(fb, lb, wn_ * WN, li_, g, h_);
+    }
+  };
+
+  // this lane's column(s) inside the tile and its byte offset inside a tile row of C (same for every tile)
+  int coln[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) coln[j] = wn * WN + (BKC ? j * 32 + li : li * TN + j);
+
+  int id = blockIdx.x;
+  int tile = xcd_remap(id, ntiles);
+  int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  typename FA::Plan pa;
+  typename FB::Plan pb;
+  float4 ra0[FA::NV], rb0[FB::NV], ra[FA::NV], rb[FB::NV];
+  FA::plan(pa, p.A, p.lda, m0, p.M, 0, p.K, tid);
+  FB::plan(pb, p.B, p.ldb, n0, p.N, 0, p.K, tid);
+  FA::run4(ra0, pa, 0, klim);
+  FB::run4(rb0, pb, 0, klim);
+  FA::run4(ra, pa, 1, klim);
+  FB::run4(rb, pb, 1, klim);
+  stamp(p, 0, tid);
+
+  while (true) {
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bias[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bias[j] = 0.f;
+    if ((EPI == EPI_STORE || EPI == EPI_GELU2 || EPI == EPI_RELU) && p.bias) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bias[j] = p.bias[min(n0 + coln[j], p.N - 1)];
+    }
+    tq = tid;
+    asm volatile("" : "+v"(tq));
+    FA::stash(ra0, smem, tq);
+    FB::stash(rb0, smem + A_TILE, tq);
+    __syncthreads();
+    const int tno = (id - (int)blockIdx.x) / (int)gridDim.x;   // (diagnostic stamps of the first two tiles: 8 + 3t loop start, + 1 loop end, + 2 stores issued)
+    if (p.stamps && tno < 2) stamp(p, 8 + 3 * tno, tid);
+    for (int kt = 0; kt < nk; ++kt) {
+      const float* la = smem + (kt & 1) * STAGE;
+      const float* lb = la + A_TILE;
+      float* wa = smem + ((kt + 1) & 1) * STAGE;
+      float fa[2][TM][4], fb[2][TN][4];
+      load_frags(fa[0], fb[0], la, lb, 0);
+      FA::stash(ra, wa, tq);
+      FB::stash(rb, wa + A_TILE, tq);
+      FA::run4(ra, pa, kt + 2, klim);
+      FB::run4(rb, pb, kt + 2, klim);
+#pragma unroll
+      for (int g = 0; g < BK / 8; ++g) {
+        if (g + 1 < BK / 8) load_frags(fa[(g + 1) & 1], fb[(g + 1) & 1], la, lb, g + 1);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][s4], fb[g & 1][j][s4], acc[i][j], 0, 0, 0);
+      }
+      sched_pattern<4 * TM * TN, FA::NV + FB::NV, TM + (BKC ? TN : (TN == 1 ? 2 : 4)), BK / 8>();
+      __syncthreads();
+    }
+    if (p.stamps && tno < 2) stamp(p, 9 + 3 * tno, tid);
+    if (tno == 0) stamp(p, 1, tid);
+
+    // ---- tile end: descriptors of this tile's outputs / side inputs; then the memory operations in the order given above
+    const int nid = id + (int)gridDim.x;
+    const bool more = nid < ntiles;
+    const int ntile = more ? xcd_remap(nid, ntiles) : 0;
+    const int nm0 = (ntile / tiles_n) * BM, nn0 = (ntile % tiles_n) * BN;
+    auto tile_rsrc = [&](const float* base, int ld) {
+      long long bytes = ((long long)(p.M - 1 - m0) * ld + (p.N - n0)) * 4;   // tile origin .. end of the matrix
+      if (bytes > 0x7FFFFFFFll) bytes = 0x7FFFFFFFll;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (long long)m0 * ld + n0), 0, (int)bytes, 0x00020000);
+    };
+    // per-lane byte offset of accumulator element r of MFMA tile (i, j): row wm*WM + i*32 + (r&3) + 8*(r>>2) + 4h, the lane's column
+    // Byte offset of accumulator element r of MFMA tile (i, j) inside the tile's row-major window: row wm*WM + i*32 + (r&3) +
+    // 8*(r>>2) + 4h, the lane's column.  The whole offset goes through the VGPR operand (the scalar offset of a buffer
+    // instruction is not range-checked); a lane whose column lies past N gets an out-of-range offset: its loads read 0, its
+    // stores are dropped.
+    bool nok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) nok[j] = n0 + coln[j] < p.N;
+    // (`hq` is made opaque per tile: otherwise LLVM hoists all TM*16*TN tile-invariant offsets out of the tile loop and keeps them
+    //  in registers through the main loop - 140-180 VGPRs instead of ~90)
+    int hq = 4 * h;
+    asm volatile("" : "+v"(hq));
+    auto voff = [&](int i, int j, int r, int ld) -> unsigned {
+      const unsigned rowpart = (unsigned)((wm * WM + i * 32 + (r & 3) + 8 * (r >> 2)) * ld * 4);   // uniform
+      const unsigned lanepart = (unsigned)((hq * ld + coln[j]) * 4);
+      return nok[j] ? rowpart + lanepart : DGVIT_OOB;
+    };
+    constexpr bool HAS_SIDE = EPI == EPI_STORE || EPI == EPI_DGELU || EPI == EPI_DRELU;
+    const bool use_side = EPI == EPI_STORE ? p.res != nullptr : HAS_SIDE;
+    if (HAS_SIDE && use_side) {
+      // side inputs of the whole tile in flight together, then folded into the accumulators (their registers are free again
+      // before the next tile's fetch is issued)
+      const float* sb = EPI == EPI_STORE ? p.res : p.aux;
+      const int sld = EPI == EPI_STORE ? p.ldr : p.ldaux;
+      const __amdgpu_buffer_rsrc_t sr = tile_rsrc(sb, sld);
+      float side[TM * 16 * TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          // (32-bit loads also where a lane owns two adjacent columns: this toolchain's __builtin_amdgcn_raw_buffer_load_b64
+          //  is lowered to a ONE-dword load - ROCm 7.2 clang - so the second column would be garbage)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            side[(i * 16 + r) * TN + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, voff(i, j, r, sld), 0, 0));
+        }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float sv = side[(i * 16 + r) * TN + j];
+            if (EPI == EPI_STORE) acc[i][j][r] += sv;                    // residual first, bias below: the order of gemm_f32_kernel
+            else if (EPI == EPI_DGELU) acc[i][j][r] *= gelu_erf_grad(sv);
+            else acc[i][j][r] = sv > 0.f ? acc[i][j][r] : 0.f;
+            if (EPI == EPI_DGELU) __builtin_amdgcn_sched_barrier(0);
+          }
+    }
+    if (more) {   // the next tile's first two k-tiles: in flight under this tile's stores
+      FA::plan(pa, p.A, p.lda, nm0, p.M, 0, p.K, tid);
+      FB::plan(pb, p.B, p.ldb, nn0, p.N, 0, p.K, tid);
+      FA::run4(ra0, pa, 0, klim);
+      FB::run4(rb0, pb, 0, klim);
+      FA::run4(ra, pa, 1, klim);
+      FB::run4(rb, pb, 1, klim);
+    }
+    {
+      const __amdgpu_buffer_rsrc_t cr = tile_rsrc(p.C, p.ldc);
+      __amdgpu_buffer_rsrc_t c2r = cr;
+      if (EPI == EPI_GELU2) c2r = tile_rsrc(p.C2, p.ldc2);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            v[j] = acc[i][j][r];
+            if (EPI == EPI_STORE || EPI == EPI_GELU2) v[j] += bias[j];
+            else if (EPI == EPI_RELU) v[j] = fmaxf(v[j] + bias[j], 0.f);
+          }
+          if constexpr (CW == 1) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), cr, voff(i, j, r, p.ldc), 0, 0);
+              if (EPI == EPI_GELU2)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gelu_erf(v[j])), c2r, voff(i, j, r, p.ldc), 0, 0);
+            }
+          } else {
+            u32x2 w;
+            w[0] = __builtin_bit_cast(unsigned, v[0]);
+            w[1] = __builtin_bit_cast(unsigned, v[1]);
+            __builtin_amdgcn_raw_buffer_store_b64(w, cr, voff(i, 0, r, p.ldc), 0, 0);
+            if (EPI == EPI_GELU2) {
+              w[0] = __builtin_bit_cast(unsigned, gelu_erf(v[0]));
+              w[1] = __builtin_bit_cast(unsigned, gelu_erf(v[1]));
+              __builtin_amdgcn_raw_buffer_store_b64(w, c2r, voff(i, 0, r, p.ldc), 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);   // one row piece at a time: keeps the scheduler from computing every value and offset first
+        }
+    }
+    if (p.stamps && tno < 2) stamp(p, 10 + 3 * tno, tid);
+    if (!more) break;
+    id = nid;
+    m0 = nm0;
+    n0 = nn0;
+  }
+  stamp(p, 2, tid);
+  stamp(p, 3, tid);
+  if (p.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(p, 7, tid);
+  }
+}
+
 // ---- in-launch split-K policy -------------------------------------------------------------------------------------------
 // (a) few tiles, long K (small batches: T = 65 ... 2080 rows against K = 2048): every tile is cut so that the grid fills the chip;
 // (b) a big grid whose last partial round would leave most CUs idle (tiles mod 256 <= 128: measured at 25600 x 256 x 2048,
@@ -683,6 +1028,39 @@ inline GemmSplitPlan split_plan(int M, int N, int K, int BM, int BN, int BK, int
   return pl;
 }
 
+template <class T, int LAYOUT, int EPI>
+int launch_persistent(const GemmParams& p, hipStream_t stream, bool* taken) {
+  *taken = false;
+  if constexpr ((LAYOUT == GEMM_NT || LAYOUT == GEMM_NN) && EPI != EPI_SPLITK && (LAYOUT == GEMM_NT || T::BN / T::WVN / 32 <= 2)) {
+    constexpr int BM = T::BM, BN = T::BN, BK = T::BK;
+    constexpr bool BKC = LAYOUT == GEMM_NT;
+    constexpr size_t lds = 2 * (BM * (BK + 4) + (BKC ? BN * (BK + 4) : BK * (BN + 4))) * sizeof(float);
+    auto kern = gemm_f32_pkernel<T, LAYOUT, EPI>;
+    static int slots = 0;
+    if (!slots) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return dgvit_set_error(DGVIT_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      int per_cu = 0;
+      e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, T::NT, lds);
+      if (e != hipSuccess || per_cu < 1) return dgvit_set_error(DGVIT_ERR_HIP, "gemm: occupancy query: %s", hipGetErrorString(e));
+      slots = 256 * per_cu;
+    }
+    const long long tiles = (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    if (g_gemm_persist == 1 && tiles < 2ll * slots) return DGVIT_OK;     // few tiles per slot: the per-tile kernel (and its tail split)
+    if (tiles >= (1ll << 31)) return DGVIT_OK;
+    GemmParams q = p;
+    q.stamps = g_gemm_stamps;
+    q.stamp_capacity = g_gemm_stamp_capacity;
+    const unsigned grid = (unsigned)std::min<long long>(tiles, g_gemm_persist_grid > 0 ? g_gemm_persist_grid : slots);
+    const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, stream);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::NT), lds, stream, q);
+    profile_end(slot, stream);
+    DGVIT_CHECK_LAUNCH("gemm_f32_pkernel");
+    *taken = true;
+  }
+  return DGVIT_OK;
+}
+
 template <class T, int LAYOUT, int VEC, int EPI, bool GATHER = false>
 int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK;
@@ -699,6 +1077,9 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
     attr_done = true;
   }
   GemmParams p = p0;
+  p.stamps = g_gemm_stamps;
+  p.stamp_capacity = g_gemm_stamp_capacity;
+  p.loop_prio = g_gemm_loop_prio;
   const long long tiles = (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   DGVIT_CHECK_ARG(tiles > 0 && tiles < (1ll << 31), "gemm: bad tile count %lld", tiles);
   long long blocks = tiles;
@@ -710,6 +1091,16 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
     if (pl.nsplit > 1 && pl.slab_floats <= p.slab_capacity && tiles <= p.counter_capacity) {
       p.nsplit = pl.nsplit; p.split_from = pl.split_from; p.kchunk_split = pl.kchunk;
       blocks = pl.split_from + (tiles - pl.split_from) * pl.nsplit;
+    }
+  }
+  if constexpr (VEC == 4 && !GATHER && EPI != EPI_SPLITK && LAYOUT != GEMM_TN) {
+    // whole tiles only, vector epilogue, plain row mapping: the persistent kernel (tile loop in the workgroup, next tile's fetch
+    // under the epilogue) when a resident slot gets several tiles
+    if (g_gemm_persist && (p.nsplit == 1 || g_gemm_persist == 2) && nsplit == 1 && p.evec && p.c_rgrp == 0 && p.res_mod == 0 &&
+        (EPI != EPI_GELU2 || p.ldc2 == p.ldc) && g_gemm_lds_pad == 0) {
+      bool taken = false;
+      const int rc = launch_persistent<T, LAYOUT, EPI>(p0, stream, &taken);
+      if (rc != DGVIT_OK || taken) return rc;
     }
   }
   dim3 grid((unsigned)blocks, 1, (unsigned)nsplit);
@@ -754,6 +1145,11 @@ inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) =
 
 int g_gemm_tile_hint = 0;  // test/bench override: 0 auto, 64, 128
 int g_gemm_lds_pad = 0;    // diagnostic: extra dynamic LDS bytes per workgroup (caps the workgroups per CU: occupancy probe)
+long long* g_gemm_stamps = nullptr;   // diagnostic: per-workgroup clock stamps of the next launches (tools/gemm_stamps.py)
+int g_gemm_stamp_capacity = 0;
+int g_gemm_loop_prio = 0;      // A/B knob: s_setprio 2 around the main loop of the per-tile kernel
+int g_gemm_persist_grid = 0;   // diagnostic: workgroups of the persistent launch (0 = resident slots)
+int g_gemm_persist = 0;        // 0 never (default: measured slower), 1 when a slot gets several tiles and nothing is split, 2 whenever eligible
 int g_gemm_split = 1;      // A/B knob: in-launch split-K of the forward / data-gradient GEMMs
 
 GemmSplitPlan gemm_split_plan(int layout, int M, int N, int K) {

@@ -37,6 +37,11 @@ int resize_bilinear(const float*, float*, int, int, int, int, int, float, hipStr
 extern int g_gemm_tile_hint;
 extern int g_gemm_split;
 extern int g_gemm_lds_pad;
+extern int g_gemm_persist;
+extern int g_gemm_loop_prio;
+extern int g_gemm_persist_grid;
+extern long long* g_gemm_stamps;
+extern int g_gemm_stamp_capacity;
 int mlp_head_forward(const dgvit_mlp_desc*, const float* const*, const float* const*, float*, float*, float*, hipStream_t);
 long long mlp_head_backward_scratch(const dgvit_mlp_desc*);
 int mlp_head_backward(const dgvit_mlp_desc*, const float* const*, const float* const*, const float*, const float*, const float* const*,

@@ -181,6 +181,19 @@ void dgvit_set_grouped_reduce(int on);
 void dgvit_set_gemm_split(int on);
 /* diagnostic: request `bytes` more dynamic LDS per fp32 GEMM workgroup than it uses (caps the workgroups per CU: occupancy probes) */
 void dgvit_set_gemm_lds_pad(int bytes);
+/* A/B knob: raise the wave priority (s_setprio 2) of the per-tile fp32 GEMM's main loop over the prologue / epilogue waves on
+ * the same SIMD.  Default 0. */
+void dgvit_set_gemm_loop_priority(int on);
+/* A/B knob: the persistent fp32 GEMM (tile loop inside the workgroup, next tile's fetch under the epilogue; NT / NN forms with
+ * 16-byte-aligned operands).  mode 0 = never, 1 (default) = when a resident workgroup slot gets at least two tiles and no tile is
+ * split, 2 = whenever the launch is eligible.  workgroups > 0 overrides the grid (diagnostic; 0 = resident slots).  Same results
+ * bit for bit: the k order of a tile does not change. */
+void dgvit_set_gemm_persistent(int mode, int workgroups);
+/* diagnostic (tools/gemm_stamps.py): non-NULL = every fp32 GEMM launch writes 16 int64 per workgroup (< `workgroups`) into the
+ * device buffer: [0..3] shader clock at kernel start / first k-tile in LDS / main loop done / stores issued, [7] stores drained (the
+ * stamped run waits for them), [4] and [6] the 100 MHz counter at start and end, [5] HW_ID | XCC_ID << 32, [8 + 2c] / [9 + 2c] epilogue chunk c: C image in
+ * LDS / stores issued.  NULL (default) = off; the product never sets it. */
+void dgvit_set_gemm_stamps(long long* stamps, int workgroups);
 /* Opt-in experiment (default OFF): dgvit_got_forward with save_for_backward == 0 and at most max_rows token rows (default
  * 4160 = 64 frames of 65 tokens) runs every transformer block as TWO launches (one workgroup per frame and head; one per
  * frame and 128-wide hidden chunk) instead of seven GEMM / LayerNorm / attention launches -- aimed at SAC.choose_action

@@ -921,3 +921,81 @@ def test_attention_backward_single_pass_equals_two_phase(B, N, H, dh):
     torch.testing.assert_close(single, two_phase, atol=2e-5, rtol=1e-5)
     again = F.op_attention_bwd(qkv, out, dout, lse, H, dh)
     assert torch.equal(single, again), "fixed summation order: bit-identical from run to run"
+
+
+# ---------------------------------------------------------------- persistent fp32 GEMM (tile loop in the workgroup)
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout,epi,M,N,K,tile,wgs", [
+    (0, 0, 1000, 384, 256, 64128016, 8),       # NT, bias + residual, ragged M, tiles walk through several rounds per workgroup
+    (0, 0, 1000, 384, 256, 64128016, 0),
+    (0, 1, 777, 512, 256, 64128016, 16),       # NT, gelu2 (two outputs)
+    (0, 3, 520, 256, 144, 64064032, 8),        # NT, relu, K not a multiple of the k-tile
+    (1, 0, 1000, 264, 512, 64064032, 8),       # NN plain, ragged N (multiple of 4, not of the tile)
+    (1, 2, 900, 512, 256, 64128016, 24),       # NN, dgelu operand
+    (1, 4, 333, 128, 64, 64064016, 8),         # NN, drelu operand
+    (0, 0, 130, 128, 2048, 128128016, 2),      # big tile, long K
+    (1, 2, 25600, 2048, 256, 0, 0),            # the C3 shapes themselves, automatic tile and grid
+    (0, 1, 25600, 2048, 256, 0, 0),
+])
+def test_persistent_gemm_equals_per_tile_kernel(layout, epi, M, N, K, tile, wgs):
+    """The persistent kernel keeps every tile's k order: results are bit-identical to the per-tile kernel's, for every epilogue,
+    ragged edges included."""
+    import dgvit_amd
+    from dgvit_amd import functional as F
+    lib = dgvit_amd.load_library()
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn(N, K, generator=g) if layout == 0 else torch.randn(K, N, generator=g)).cuda()
+    bias = torch.randn(N, generator=g).cuda() if layout == 0 else None
+    res = torch.randn(M, N, generator=g).cuda() if (layout == 0 and epi == 0) else None
+    aux = torch.randn(M, N, generator=g).cuda() if epi in (2, 4) else None
+
+    def run(mode):
+        lib.dgvit_set_gemm_tile(tile)
+        lib.dgvit_set_gemm_persistent(mode, wgs)
+        lib.dgvit_set_gemm_split(0)          # (split tiles sum their k-slices in another order: not the comparison made here)
+        try:
+            out = F.op_gemm(layout, epi, A, B, M, N, K, bias=bias, res=res, aux=aux, want_c2=(epi == 1))
+            torch.cuda.synchronize()
+        finally:
+            lib.dgvit_set_gemm_tile(0)
+            lib.dgvit_set_gemm_persistent(0, 0)
+            lib.dgvit_set_gemm_split(1)
+        return out if isinstance(out, tuple) else (out,)
+
+    ref = run(0)
+    got = run(2)
+    for r, o in zip(ref, got):
+        assert torch.isfinite(o).all()
+        assert torch.equal(r, o), f"max diff {(r - o).abs().max().item()}"
+
+
+@pytest.mark.gpu
+def test_persistent_gemm_writes_nothing_outside_c():
+    """Direct accumulator stores with the descriptor's range check: a C window inside a larger canary buffer stays intact around
+    the matrix (rows past M and the columns between N and ldc)."""
+    import dgvit_amd
+    from dgvit_amd import _lib
+    lib = dgvit_amd.load_library()
+    M, N, K, ldc = 203, 132, 256, 160
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = torch.randn(N, K, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    pad = 4096
+    buf = torch.full((pad + M * ldc + pad,), 777.0, device="cuda")
+    C = buf[pad:pad + M * ldc].view(M, ldc)
+    nsc = lib.dgvit_gemm_scratch_floats(0, M, N, K)
+    scratch = torch.zeros(max(nsc, 4), device="cuda")
+    lib.dgvit_set_gemm_persistent(2, 3)
+    try:
+        rc = lib.dgvit_gemm(0, 0, A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), ldc, M, N, K, bias.data_ptr(), None, 0, None, 0, None, 0,
+                            scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream)
+    finally:
+        lib.dgvit_set_gemm_persistent(0, 0)
+    _lib.check(rc, "dgvit_gemm")
+    torch.cuda.synchronize()
+    ref = (A.double() @ B.double().t() + bias.double()).float()
+    torch.testing.assert_close(C[:, :N], ref, atol=2e-4, rtol=1e-5)
+    assert (C[:, N:] == 777.0).all(), "columns between N and ldc were written"
+    assert (buf[:pad] == 777.0).all() and (buf[pad + M * ldc:] == 777.0).all(), "wrote outside C"

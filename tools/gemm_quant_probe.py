@@ -7,6 +7,11 @@ import torch
 import dgvit_amd
 from dgvit_amd import functional as F
 lib = dgvit_amd.load_library()
+if "PERSIST" in os.environ:
+    lib.dgvit_set_gemm_persistent(int(os.environ["PERSIST"]), int(os.environ.get("PGRID", 0)))
+if "LOOPPRIO" in os.environ:
+    lib.dgvit_set_gemm_loop_priority(int(os.environ["LOOPPRIO"]))
+MS = [int(x) for x in os.environ["MS"].split(",")] if "MS" in os.environ else (8192, 12288, 16384, 20480, 24576, 25600, 28672, 32768, 65536)
 dev = "cuda"
 
 
@@ -36,7 +41,7 @@ CASES = [("fc2 fwd  NT N=256 K=2048 64x64x32", 0, 0, 256, 2048, 64064032, 64, 64
          ("fc1 fwd  NT N=2048 K=256 64x128x16 gelu2", 0, 1, 2048, 256, 64128016, 64, 128),
          ("dfc2     NN N=2048 K=256 64x128x16 dgelu", 1, 2, 2048, 256, 64128016, 64, 128)]
 for name, layout, epi, n, k, hint, bm, bn in CASES:
-    for m in (8192, 12288, 16384, 20480, 24576, 25600, 28672, 32768, 65536):
+    for m in MS:
         ms = timeit(layout, epi, m, n, k, hint)
         tiles = (m // bm) * (n // bn)
         tf = 2.0 * m * n * k / ms / 1e9
