@@ -61,6 +61,7 @@ SIGNATURES = {
     "dgvit_set_gemm_lds_pad": (None, [_I]),
     "dgvit_set_gemm_loop_priority": (None, [_I]),
     "dgvit_set_gemm_persistent": (None, [_I, _I]),
+    "dgvit_gemm_persistent_launches": (ctypes.c_longlong, []),
     "dgvit_set_gemm_stamps": (None, [_P, _I]),
     "dgvit_set_small_batch_path": (None, [_I, _I]),
     "dgvit_layernorm_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),

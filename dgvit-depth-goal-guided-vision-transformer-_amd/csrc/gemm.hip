@@ -36,6 +36,7 @@ extern int g_gemm_split;
 extern int g_gemm_lds_pad;
 extern int g_gemm_persist;
 extern int g_gemm_persist_grid;
+extern long long g_gemm_persist_launches;
 extern int g_gemm_loop_prio;
 extern long long* g_gemm_stamps;
 extern int g_gemm_stamp_capacity;
@@ -405,7 +406,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
     }
     __syncthreads();
     stamp(p, 1, tid);
-    if (p.loop_prio) __builtin_amdgcn_s_setprio(2);   // A/B knob: main-loop waves ahead of the prologue / epilogue waves they share a SIMD with
+    if (p.loop_prio & 1) __builtin_amdgcn_s_setprio(2);   // A/B knob: main-loop waves ahead of the prologue / epilogue waves they share a SIMD with
     for (int kt = 0; kt < nk; ++kt) {
       const float* la = smem + (kt & 1) * STAGE;
       const float* lb = la + A_TILE;
@@ -430,7 +431,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
       }
       __syncthreads();
     }
-    if (p.loop_prio) __builtin_amdgcn_s_setprio(0);
+    if (p.loop_prio & 1) __builtin_amdgcn_s_setprio(0);
   } else {
     FA::run(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
     FB::run(rb, p.B, p.ldb, n0, p.N, kbeg, kend, tid);
@@ -461,6 +462,17 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   }
 
   stamp(p, 2, tid);
+  if (p.loop_prio & 2) {   // diagnostic (dgvit_set_gemm_loop_priority(2)): main loop only - what would a free epilogue be worth?
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 1.2345678e33f) p.C[0] = sacc;
+    return;
+  }
   // ---- epilogue ------------------------------------------------------------------------------------
   float* Cz = p.C;
   if (EPI == EPI_SPLITK) {
@@ -629,8 +641,13 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
         if (m < p.M && nvalid) {
           long long crow = m;
           if (EPI == EPI_STORE && p.c_rgrp > 0) crow = (long long)m + m / p.c_rgrp + 1;
-          *reinterpret_cast<float4*>(Cz + crow * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-          if (EPI == EPI_GELU2) *reinterpret_cast<float4*>(p.C2 + (long long)m * p.ldc2 + n) = make_float4(w2[0], w2[1], w2[2], w2[3]);
+          int ncol = n;
+          if (p.loop_prio & 4) {   // diagnostic: every tile stores over tile 0 (the same instructions, no HBM write stream; results garbage)
+            crow = m - m0;
+            ncol = cc;
+          }
+          *reinterpret_cast<float4*>(Cz + crow * p.ldc + ncol) = make_float4(v[0], v[1], v[2], v[3]);
+          if (EPI == EPI_GELU2) *reinterpret_cast<float4*>(p.C2 + crow * p.ldc2 + ncol) = make_float4(w2[0], w2[1], w2[2], w2[3]);
         }
       }
     } else if (n < p.N) {
@@ -755,32 +772,42 @@ __global__ void __launch_bounds__(256) reduce_slabs_scalar_kernel(const float* _
   else out2[i - n1] = s;
 }
 
-// ---- persistent variant: tile loop inside the workgroup, next tile's fetch under the epilogue ----------------------------------
-// Stamps of the per-tile kernel (tools/gemm_stamps.py, profiles/r02_c_*) at the K = 256 shapes: a workgroup spends ~15 % of its
-// life waiting for its first two k-tiles (one loaded-memory round trip, 8-15 k cycles) and ~25 % in the epilogue, and only the
-// remaining ~60 % in the main loop, where the MFMA pipe is ~94 % busy.  With 5 resident workgroups per CU that is the 0.79 pipe use
-// the counters show.  Here a workgroup walks over several tiles (grid = resident slots; tile id += gridDim.x, same XCD-contiguous
-// order), and between the main loop and the epilogue of tile t it issues the fetch of tile t+1's first two k-tiles; the epilogue
-// stores the accumulators straight from registers (buffer stores: a lane's 32-bit (NT) or 64-bit (NN) pieces, 128 / 256
-// contiguous bytes per half-wave; rows past M dropped by the descriptor's range check, columns past N by an out-of-range
-// offset), so the LDS stages are free for the next tile and no barrier separates a tile's stores from the next tile's loop.
-// Order of memory operations per tile end (vmcnt retires in order on gfx9, so nothing may wait behind a store):
-//   side-input loads (residual / activation-gradient operand), folded into the accumulators -> next tile's fetch -> stores.
-// NT and NN forms, 16-byte-aligned operands, no row remap / residual broadcast / split tiles (those stay on gemm_f32_kernel).
+// ---- pipelined persistent variant: one continuous k-tile stream per workgroup, a tile's stores under the next tile's MFMAs -----
+// What the per-tile kernel loses at the K = 256 shapes (45 % of the step's GEMM time) is its epilogue: with the stores skipped
+// (diagnostic bit of dgvit_set_gemm_loop_priority) QKV / fc1 / fc2-dgrad run at 133-135 TFLOP/s instead of 101-107
+// (profiles/r02_c_gemm_no_epilogue_bound.txt).  Shortening the epilogue did not help (the time reappears as waiting elsewhere), and
+// a persistent tile loop that keeps epilogue and main loop as separate phases is slower still: all workgroups of the chip fall into
+// step and store at the same moment (profiles/r02_c_gemm_persistent_kernel_negative_result.txt).  So here there are no phases:
+//   * the workgroup walks over its tiles (tile id += gridDim.x, same XCD-contiguous order) with ONE k-tile pipeline: iteration kt
+//     of a tile fetches k-tile kt + 2 - of the NEXT tile for the last two iterations - so there is no prologue after the first;
+//   * the finished tile's accumulators are copied to a second register set and leave during the next tile's main loop, one
+//     accumulator row piece (TN values per lane and MFMA row tile) per iteration: buffer stores straight from registers (a lane's
+//     32-bit (NT) or 64-bit (NN) pieces, 128 / 256 contiguous bytes per half-wave; rows past M dropped by the descriptor's range
+//     check, columns past N and the not-yet-existing previous tile of the first round by an out-of-range offset - no branch);
+//   * side inputs (residual / activation-gradient operand) of piece r are requested two iterations before they are used, the
+//     first two pieces during the tile's own last two iterations.
+// The k-tile count is a compile-time constant (NK = 16: K = 256 with 16-deep and K = 512 with 32-deep k-tiles) and the main loop is
+// fully unrolled, which is what gives every iteration ITS accumulator registers to drain.  Memory operations of one iteration, in
+// program order: operand fetch, side-input request, stores - vmcnt retires in order on gfx9, so every wait the compiler needs is for
+// something older than the stores around it.  64 accumulator registers: 4 workgroups per CU instead of 5.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <class T, int LAYOUT, int EPI>
-__global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_pkernel(const GemmParams p) {
+template <class T, int LAYOUT, int EPI, int NK>
+__global__ void __launch_bounds__(T::NT, T::LDS_BYTES * 4 <= 160 * 1024 ? 4 : 2) gemm_f32_pipe_kernel(const GemmParams p) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NT;
-  static_assert(LAYOUT == GEMM_NT || LAYOUT == GEMM_NN, "persistent GEMM: forward / data-gradient forms");
-  static_assert(EPI != EPI_SPLITK, "persistent GEMM: complete-K tiles");
+  static_assert(LAYOUT == GEMM_NT || LAYOUT == GEMM_NN, "pipelined GEMM: forward / data-gradient forms");
+  static_assert(EPI != EPI_SPLITK && NK % 2 == 0 && NK >= 4, "pipelined GEMM: complete-K tiles, even k-tile count");
   constexpr bool BKC = LAYOUT == GEMM_NT;
   constexpr int WM = BM / T::WVM, WN = BN / T::WVN, TM = WM / 32, TN = WN / 32;
+  static_assert(16 % NK == 0 || NK % 16 == 0, "pipelined GEMM: accumulator rows per iteration");
+  constexpr int RPI = NK >= 16 ? 1 : 16 / NK;     // accumulator rows (r) drained per iteration
+  constexpr int DRAIN_EVERY = NK >= 16 ? NK / 16 : 1;
   constexpr int A_TILE = BM * (BK + 4);
   constexpr int B_TILE = BKC ? BN * (BK + 4) : BK * (BN + 4);
   constexpr int STAGE = A_TILE + B_TILE;
   constexpr int CW = BKC ? 1 : TN;            // floats per store: NT one column per MFMA tile, NN the lane's TN adjacent columns
-  static_assert(CW == 1 || CW == 2, "persistent GEMM: one or two adjacent columns per lane");
+  static_assert(CW == 1 || CW == 2, "pipelined GEMM: one or two adjacent columns per lane");
+  constexpr bool HAS_SIDE = EPI == EPI_STORE || EPI == EPI_DGELU || EPI == EPI_DRELU;
   using FA = Fetch<BM, BK, true, 4, NT>;
   using FB = Fetch<BN, BK, BKC, 4, NT>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -789,44 +816,142 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_pkernel(const GemmPar
   const int li = lane & 31, h = lane >> 5;
   const int wm = wave / T::WVN, wn = wave % T::WVN;
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
-  const int nk = (p.K + BK - 1) / BK, klim = p.K;
+  constexpr int klim = NK * BK;               // == p.K (checked at launch)
 
-  // (lane coordinates of the main loop are re-derived from an opaque copy of the thread id at every tile, see `tq` below: LDS
-  //  addresses are then computed per tile instead of living in registers across the epilogue, where the accumulators, the next
-  //  tile's fetch and the store offsets need the room)
-  int tq = tid;
   auto load_frags = [&](float (&fa)[TM][4], float (&fb)[TN][4], const float* la, const float* lb, int g) {
-    const int li_ = tq & 31, h_ = (tq >> 5) & 1, wm_ = (tq >> 6) / T::WVN, wn_ = (tq >> 6) % T::WVN;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) frag<BM, BK, true>(fa[i], la, wm_ * WM + i * 32 + li_, g, h_);
+    for (int i = 0; i < TM; ++i) frag<BM, BK, true>(fa[i], la, wm * WM + i * 32 + li, g, h);
     if constexpr (BKC) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) frag<BN, BK, true>(fb[j], lb, wn_ * WN + j * 32 + li_, g, h_);
+      for (int j = 0; j < TN; ++j) frag<BN, BK, true>(fb[j], lb, wn * WN + j * 32 + li, g, h);
     } else {
-      frag_mc<BN, TN>(fb, lb, wn_ * WN, li_, g, h_);
+      frag_mc<BN, TN>(fb, lb, wn * WN, li, g, h);
     }
   };
-
-  // this lane's column(s) inside the tile and its byte offset inside a tile row of C (same for every tile)
-  int coln[TN];
+  int coln[TN];   // this lane's column(s) inside a tile
 #pragma unroll
   for (int j = 0; j < TN; ++j) coln[j] = wn * WN + (BKC ? j * 32 + li : li * TN + j);
+  const bool use_side = HAS_SIDE && (EPI == EPI_STORE ? p.res != nullptr : true);
+  const float* side_base = EPI == EPI_STORE ? p.res : p.aux;
+  const int sld = EPI == EPI_STORE ? p.ldr : p.ldaux;
+
+  // window of one tile in a row-major matrix: tile origin .. end of the matrix (rows past M fall outside, columns are predicated)
+  auto tile_rsrc = [&](const float* base, int ld, int m0, int n0) {
+    long long bytes = ((long long)(p.M - 1 - m0) * ld + (p.N - n0)) * 4;
+    if (bytes > 0x7FFFFFFFll) bytes = 0x7FFFFFFFll;
+    if (bytes < 0) bytes = 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (long long)m0 * ld + n0), 0, (int)bytes, 0x00020000);
+  };
+  // byte offset of accumulator element r of MFMA tile (i, j) inside that window (all of it in the VGPR operand: the scalar offset of
+  // a buffer instruction is not range-checked); `lanepart` is DGVIT_OOB for a lane that must not touch memory
+  auto elem_off = [&](unsigned lanepart, int i, int r, int ld) -> unsigned {
+    const unsigned rowpart = (unsigned)((wm * WM + i * 32 + (r & 3) + 8 * (r >> 2)) * ld * 4);   // uniform
+    return lanepart == DGVIT_OOB ? DGVIT_OOB : rowpart + lanepart;
+  };
 
   int id = blockIdx.x;
   int tile = xcd_remap(id, ntiles);
   int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  typename FA::Plan pa;
-  typename FB::Plan pb;
-  float4 ra0[FA::NV], rb0[FB::NV], ra[FA::NV], rb[FB::NV];
+  typename FA::Plan pa, pan;
+  typename FB::Plan pb, pbn;
+  float4 ra[FA::NV], rb[FB::NV];
   FA::plan(pa, p.A, p.lda, m0, p.M, 0, p.K, tid);
   FB::plan(pb, p.B, p.ldb, n0, p.N, 0, p.K, tid);
-  FA::run4(ra0, pa, 0, klim);
-  FB::run4(rb0, pb, 0, klim);
-  FA::run4(ra, pa, 1, klim);
-  FB::run4(rb, pb, 1, klim);
+  {   // the only prologue: k-tiles 0 and 1 of the first tile
+    float4 ra0[FA::NV], rb0[FB::NV];
+    FA::run4(ra0, pa, 0, klim);
+    FB::run4(rb0, pb, 0, klim);
+    FA::run4(ra, pa, 1, klim);
+    FB::run4(rb, pb, 1, klim);
+    FA::stash(ra0, smem, tid);
+    FB::stash(rb0, smem + A_TILE, tid);
+  }
+  __syncthreads();
   stamp(p, 0, tid);
 
+  // the tile that is leaving: accumulators, bias, lane offsets (DGVIT_OOB until a first tile has finished), descriptors
+  f32x16 prev[TM][TN];
+  float bias_p[TN];
+  unsigned lane_c[TN], lane_s[TN];   // lane part of the offsets into C (and C2) / the side input, or DGVIT_OOB
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    bias_p[j] = 0.f;
+    lane_c[j] = DGVIT_OOB;
+    lane_s[j] = DGVIT_OOB;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) prev[i][j][r] = 0.f;
+  }
+  __amdgpu_buffer_rsrc_t c_rs = tile_rsrc(p.C, p.ldc, m0, n0), c2_rs = c_rs, s_rs = c_rs;
+  float sd[16][TM][TN];   // side inputs of the leaving tile, by accumulator row (live from request to use only)
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) sd[r][i][j] = 0.f;
+
+  // request the side inputs of accumulator row r of the tile at (sm0, sn0): descriptor `rs`, lane parts `ls`
+  auto side_request = [&](int r, const __amdgpu_buffer_rsrc_t& rs, const unsigned (&ls)[TN]) {
+    if constexpr (HAS_SIDE) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          sd[r][i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, elem_off(ls[j], i, r, sld), 0, 0));
+    }
+  };
+  // store accumulator row r of the leaving tile
+  auto drain_row = [&](int r) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float v[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        v[j] = prev[i][j][r];
+        if (EPI == EPI_STORE) {
+          if (use_side) v[j] += sd[r][i][j];          // residual first, then bias: the order of gemm_f32_kernel
+          v[j] += bias_p[j];
+        } else if (EPI == EPI_GELU2) {
+          v[j] += bias_p[j];
+        } else if (EPI == EPI_RELU) {
+          v[j] = fmaxf(v[j] + bias_p[j], 0.f);
+        } else if (EPI == EPI_DGELU) {
+          v[j] *= gelu_erf_grad(sd[r][i][j]);
+        } else if (EPI == EPI_DRELU) {
+          v[j] = sd[r][i][j] > 0.f ? v[j] : 0.f;
+        }
+      }
+      if constexpr (CW == 1) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), c_rs, elem_off(lane_c[j], i, r, p.ldc), 0, 0);
+          if (EPI == EPI_GELU2)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gelu_erf(v[j])), c2_rs, elem_off(lane_c[j], i, r, p.ldc), 0, 0);
+        }
+      } else {
+        u32x2 w;
+        w[0] = __builtin_bit_cast(unsigned, v[0]);
+        w[1] = __builtin_bit_cast(unsigned, v[1]);
+        __builtin_amdgcn_raw_buffer_store_b64(w, c_rs, elem_off(lane_c[0], i, r, p.ldc), 0, 0);
+        if (EPI == EPI_GELU2) {
+          w[0] = __builtin_bit_cast(unsigned, gelu_erf(v[0]));
+          w[1] = __builtin_bit_cast(unsigned, gelu_erf(v[1]));
+          __builtin_amdgcn_raw_buffer_store_b64(w, c2_rs, elem_off(lane_c[0], i, r, p.ldc), 0, 0);
+        }
+      }
+    }
+  };
+
   while (true) {
+    // ---- tile (m0, n0): its plans are pa / pb and its first two k-tiles are on their way (stage 0 in LDS, k-tile 1 in ra / rb)
+    const int nid = id + (int)gridDim.x;
+    const bool more = nid < ntiles;
+    const int ntile = more ? xcd_remap(nid, ntiles) : 0;
+    const int nm0 = (ntile / tiles_n) * BM, nn0 = (ntile % tiles_n) * BN;
+    FA::plan(pan, p.A, p.lda, nm0, more ? p.M : 0, 0, p.K, tid);      // no next tile: an empty window, the fetches read 0
+    FB::plan(pbn, p.B, p.ldb, nn0, more ? p.N : 0, 0, p.K, tid);
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -834,30 +959,60 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_pkernel(const GemmPar
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float bias[TN];
+    float bias_c[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bias[j] = 0.f;
+    for (int j = 0; j < TN; ++j) bias_c[j] = 0.f;
     if ((EPI == EPI_STORE || EPI == EPI_GELU2 || EPI == EPI_RELU) && p.bias) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bias[j] = p.bias[min(n0 + coln[j], p.N - 1)];
+      for (int j = 0; j < TN; ++j) bias_c[j] = p.bias[min(n0 + coln[j], p.N - 1)];
     }
-    tq = tid;
-    asm volatile("" : "+v"(tq));
-    FA::stash(ra0, smem, tq);
-    FB::stash(rb0, smem + A_TILE, tq);
-    __syncthreads();
-    const int tno = (id - (int)blockIdx.x) / (int)gridDim.x;   // (diagnostic stamps of the first two tiles: 8 + 3t loop start, + 1 loop end, + 2 stores issued)
-    if (p.stamps && tno < 2) stamp(p, 8 + 3 * tno, tid);
-    for (int kt = 0; kt < nk; ++kt) {
+    // this tile's own output window and lane offsets (used for its first side requests now, for its stores during the next tile)
+    const __amdgpu_buffer_rsrc_t cur_c = tile_rsrc(p.C, p.ldc, m0, n0);
+    __amdgpu_buffer_rsrc_t cur_s = cur_c;
+    if (HAS_SIDE && use_side) cur_s = tile_rsrc(side_base, sld, m0, n0);
+    unsigned cur_lane_c[TN], cur_lane_s[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const bool ok = n0 + coln[j] < p.N;
+      cur_lane_c[j] = ok ? (unsigned)((4 * h * p.ldc + coln[j]) * 4) : DGVIT_OOB;
+      cur_lane_s[j] = (ok && use_side) ? (unsigned)((4 * h * sld + coln[j]) * 4) : DGVIT_OOB;
+    }
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
       const float* la = smem + (kt & 1) * STAGE;
       const float* lb = la + A_TILE;
       float* wa = smem + ((kt + 1) & 1) * STAGE;
       float fa[2][TM][4], fb[2][TN][4];
       load_frags(fa[0], fb[0], la, lb, 0);
-      FA::stash(ra, wa, tq);
-      FB::stash(rb, wa + A_TILE, tq);
-      FA::run4(ra, pa, kt + 2, klim);
-      FB::run4(rb, pb, kt + 2, klim);
+      FA::stash(ra, wa, tid);
+      FB::stash(rb, wa + A_TILE, tid);
+      if (kt + 2 < NK) {
+        FA::run4(ra, pa, kt + 2, klim);
+        FB::run4(rb, pb, kt + 2, klim);
+      } else {   // the stream runs on into the next tile
+        FA::run4(ra, pan, kt + 2 - NK, klim);
+        FB::run4(rb, pbn, kt + 2 - NK, klim);
+      }
+      // side inputs: rows of the leaving tile two drain steps ahead; its first two rows were requested by its own last iterations
+      if constexpr (HAS_SIDE) {
+        if (kt % DRAIN_EVERY == 0) {
+#pragma unroll
+          for (int q = 0; q < RPI; ++q) {
+            const int r = (kt / DRAIN_EVERY) * RPI + q + 2 * RPI;
+            if (r < 16) side_request(r, s_rs, lane_s);
+          }
+        }
+      }
+      if (kt % DRAIN_EVERY == 0) {
+#pragma unroll
+        for (int q = 0; q < RPI; ++q) drain_row((kt / DRAIN_EVERY) * RPI + q);
+      }
+      if constexpr (HAS_SIDE) {
+        if (kt >= NK - 2 * DRAIN_EVERY && kt % DRAIN_EVERY == 0) {   // ... of THIS tile, for its first two drain steps in the next one
+#pragma unroll
+          for (int q = 0; q < RPI; ++q) side_request(((kt - (NK - 2 * DRAIN_EVERY)) / DRAIN_EVERY) * RPI + q, cur_s, cur_lane_s);
+        }
+      }
 #pragma unroll
       for (int g = 0; g < BK / 8; ++g) {
         if (g + 1 < BK / 8) load_frags(fa[(g + 1) & 1], fb[(g + 1) & 1], la, lb, g + 1);
@@ -869,122 +1024,39 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_pkernel(const GemmPar
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][s4], fb[g & 1][j][s4], acc[i][j], 0, 0, 0);
       }
-      sched_pattern<4 * TM * TN, FA::NV + FB::NV, TM + (BKC ? TN : (TN == 1 ? 2 : 4)), BK / 8>();
+      // (no sched_group_barrier pattern here: with it the side-input variants spill 230-270 registers and every variant measured
+      //  slower; and without a sched_barrier per iteration the group solver does not finish on the unrolled body)
       __syncthreads();
     }
-    if (p.stamps && tno < 2) stamp(p, 9 + 3 * tno, tid);
-    if (tno == 0) stamp(p, 1, tid);
-
-    // ---- tile end: descriptors of this tile's outputs / side inputs; then the memory operations in the order given above
-    const int nid = id + (int)gridDim.x;
-    const bool more = nid < ntiles;
-    const int ntile = more ? xcd_remap(nid, ntiles) : 0;
-    const int nm0 = (ntile / tiles_n) * BM, nn0 = (ntile % tiles_n) * BN;
-    auto tile_rsrc = [&](const float* base, int ld) {
-      long long bytes = ((long long)(p.M - 1 - m0) * ld + (p.N - n0)) * 4;   // tile origin .. end of the matrix
-      if (bytes > 0x7FFFFFFFll) bytes = 0x7FFFFFFFll;
-      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (long long)m0 * ld + n0), 0, (int)bytes, 0x00020000);
-    };
-    // per-lane byte offset of accumulator element r of MFMA tile (i, j): row wm*WM + i*32 + (r&3) + 8*(r>>2) + 4h, the lane's column
-    // Byte offset of accumulator element r of MFMA tile (i, j) inside the tile's row-major window: row wm*WM + i*32 + (r&3) +
-    // 8*(r>>2) + 4h, the lane's column.  The whole offset goes through the VGPR operand (the scalar offset of a buffer
-    // instruction is not range-checked); a lane whose column lies past N gets an out-of-range offset: its loads read 0, its
-    // stores are dropped.
-    bool nok[TN];
+    // ---- the tile becomes the leaving one
 #pragma unroll
-    for (int j = 0; j < TN; ++j) nok[j] = n0 + coln[j] < p.N;
-    // (`hq` is made opaque per tile: otherwise LLVM hoists all TM*16*TN tile-invariant offsets out of the tile loop and keeps them
-    //  in registers through the main loop - 140-180 VGPRs instead of ~90)
-    int hq = 4 * h;
-    asm volatile("" : "+v"(hq));
-    auto voff = [&](int i, int j, int r, int ld) -> unsigned {
-      const unsigned rowpart = (unsigned)((wm * WM + i * 32 + (r & 3) + 8 * (r >> 2)) * ld * 4);   // uniform
-      const unsigned lanepart = (unsigned)((hq * ld + coln[j]) * 4);
-      return nok[j] ? rowpart + lanepart : DGVIT_OOB;
-    };
-    constexpr bool HAS_SIDE = EPI == EPI_STORE || EPI == EPI_DGELU || EPI == EPI_DRELU;
-    const bool use_side = EPI == EPI_STORE ? p.res != nullptr : HAS_SIDE;
-    if (HAS_SIDE && use_side) {
-      // side inputs of the whole tile in flight together, then folded into the accumulators (their registers are free again
-      // before the next tile's fetch is issued)
-      const float* sb = EPI == EPI_STORE ? p.res : p.aux;
-      const int sld = EPI == EPI_STORE ? p.ldr : p.ldaux;
-      const __amdgpu_buffer_rsrc_t sr = tile_rsrc(sb, sld);
-      float side[TM * 16 * TN];
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j) prev[i][j] = acc[i][j];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          // (32-bit loads also where a lane owns two adjacent columns: this toolchain's __builtin_amdgcn_raw_buffer_load_b64
-          //  is lowered to a ONE-dword load - ROCm 7.2 clang - so the second column would be garbage)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            side[(i * 16 + r) * TN + j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, voff(i, j, r, sld), 0, 0));
-        }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float sv = side[(i * 16 + r) * TN + j];
-            if (EPI == EPI_STORE) acc[i][j][r] += sv;                    // residual first, bias below: the order of gemm_f32_kernel
-            else if (EPI == EPI_DGELU) acc[i][j][r] *= gelu_erf_grad(sv);
-            else acc[i][j][r] = sv > 0.f ? acc[i][j][r] : 0.f;
-            if (EPI == EPI_DGELU) __builtin_amdgcn_sched_barrier(0);
-          }
+    for (int j = 0; j < TN; ++j) {
+      bias_p[j] = bias_c[j];
+      lane_c[j] = cur_lane_c[j];
+      lane_s[j] = cur_lane_s[j];
     }
-    if (more) {   // the next tile's first two k-tiles: in flight under this tile's stores
-      FA::plan(pa, p.A, p.lda, nm0, p.M, 0, p.K, tid);
-      FB::plan(pb, p.B, p.ldb, nn0, p.N, 0, p.K, tid);
-      FA::run4(ra0, pa, 0, klim);
-      FB::run4(rb0, pb, 0, klim);
-      FA::run4(ra, pa, 1, klim);
-      FB::run4(rb, pb, 1, klim);
-    }
-    {
-      const __amdgpu_buffer_rsrc_t cr = tile_rsrc(p.C, p.ldc);
-      __amdgpu_buffer_rsrc_t c2r = cr;
-      if (EPI == EPI_GELU2) c2r = tile_rsrc(p.C2, p.ldc2);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v[TN];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            v[j] = acc[i][j][r];
-            if (EPI == EPI_STORE || EPI == EPI_GELU2) v[j] += bias[j];
-            else if (EPI == EPI_RELU) v[j] = fmaxf(v[j] + bias[j], 0.f);
-          }
-          if constexpr (CW == 1) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), cr, voff(i, j, r, p.ldc), 0, 0);
-              if (EPI == EPI_GELU2)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gelu_erf(v[j])), c2r, voff(i, j, r, p.ldc), 0, 0);
-            }
-          } else {
-            u32x2 w;
-            w[0] = __builtin_bit_cast(unsigned, v[0]);
-            w[1] = __builtin_bit_cast(unsigned, v[1]);
-            __builtin_amdgcn_raw_buffer_store_b64(w, cr, voff(i, 0, r, p.ldc), 0, 0);
-            if (EPI == EPI_GELU2) {
-              w[0] = __builtin_bit_cast(unsigned, gelu_erf(v[0]));
-              w[1] = __builtin_bit_cast(unsigned, gelu_erf(v[1]));
-              __builtin_amdgcn_raw_buffer_store_b64(w, c2r, voff(i, 0, r, p.ldc), 0, 0);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);   // one row piece at a time: keeps the scheduler from computing every value and offset first
-        }
-    }
-    if (p.stamps && tno < 2) stamp(p, 10 + 3 * tno, tid);
+    c_rs = cur_c;
+    s_rs = cur_s;
+    if (EPI == EPI_GELU2) c2_rs = tile_rsrc(p.C2, p.ldc2, m0, n0);
     if (!more) break;
     id = nid;
     m0 = nm0;
     n0 = nn0;
+    pa = pan;
+    pb = pbn;
   }
   stamp(p, 2, tid);
+  // ---- the last tile leaves without a main loop to hide under
+  if constexpr (HAS_SIDE) {
+#pragma unroll
+    for (int r = 2 * RPI; r < 16; ++r) side_request(r, s_rs, lane_s);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) drain_row(r);
   stamp(p, 3, tid);
   if (p.stamps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1031,11 +1103,14 @@ inline GemmSplitPlan split_plan(int M, int N, int K, int BM, int BN, int BK, int
 template <class T, int LAYOUT, int EPI>
 int launch_persistent(const GemmParams& p, hipStream_t stream, bool* taken) {
   *taken = false;
-  if constexpr ((LAYOUT == GEMM_NT || LAYOUT == GEMM_NN) && EPI != EPI_SPLITK && (LAYOUT == GEMM_NT || T::BN / T::WVN / 32 <= 2)) {
+  constexpr int NK = 16;   // k-tiles per output tile the pipelined kernel is built for: K = 256 at BK = 16, K = 512 at BK = 32
+  // built for the two tiles the automatic choice uses in these forms (every instantiation is a fully unrolled 16-iteration loop)
+  constexpr bool TILE_OK = (T::BM == 64 && T::BN == 128 && T::BK == 16) || (T::BM == 64 && T::BN == 64 && T::BK == 32);
+  if constexpr ((LAYOUT == GEMM_NT || LAYOUT == GEMM_NN) && EPI != EPI_SPLITK && TILE_OK) {
     constexpr int BM = T::BM, BN = T::BN, BK = T::BK;
-    constexpr bool BKC = LAYOUT == GEMM_NT;
-    constexpr size_t lds = 2 * (BM * (BK + 4) + (BKC ? BN * (BK + 4) : BK * (BN + 4))) * sizeof(float);
-    auto kern = gemm_f32_pkernel<T, LAYOUT, EPI>;
+    if (p.K != NK * BK) return DGVIT_OK;
+    constexpr size_t lds = T::LDS_BYTES;
+    auto kern = gemm_f32_pipe_kernel<T, LAYOUT, EPI, NK>;
     static int slots = 0;
     if (!slots) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1051,11 +1126,20 @@ int launch_persistent(const GemmParams& p, hipStream_t stream, bool* taken) {
     GemmParams q = p;
     q.stamps = g_gemm_stamps;
     q.stamp_capacity = g_gemm_stamp_capacity;
-    const unsigned grid = (unsigned)std::min<long long>(tiles, g_gemm_persist_grid > 0 ? g_gemm_persist_grid : slots);
+    // equal shares: rounds = ceil(tiles / slots) tiles per workgroup, as few workgroups as that needs (a multiple of 8 for the XCD order)
+    long long grid = slots;
+    if (g_gemm_persist_grid > 0) {
+      grid = g_gemm_persist_grid;
+    } else if (tiles > slots) {
+      const long long rounds = (tiles + slots - 1) / slots;
+      grid = std::min<long long>(slots, ((tiles + rounds - 1) / rounds + 7) / 8 * 8);
+    }
+    grid = std::min<long long>(grid, tiles);
     const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, stream);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::NT), lds, stream, q);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(T::NT), lds, stream, q);
     profile_end(slot, stream);
-    DGVIT_CHECK_LAUNCH("gemm_f32_pkernel");
+    DGVIT_CHECK_LAUNCH("gemm_f32_pipe_kernel");
+    ++g_gemm_persist_launches;
     *taken = true;
   }
   return DGVIT_OK;
@@ -1148,6 +1232,7 @@ int g_gemm_lds_pad = 0;    // diagnostic: extra dynamic LDS bytes per workgroup 
 long long* g_gemm_stamps = nullptr;   // diagnostic: per-workgroup clock stamps of the next launches (tools/gemm_stamps.py)
 int g_gemm_stamp_capacity = 0;
 int g_gemm_loop_prio = 0;      // A/B knob: s_setprio 2 around the main loop of the per-tile kernel
+long long g_gemm_persist_launches = 0;   // launches that took the pipelined kernel (tests check that they exercise it)
 int g_gemm_persist_grid = 0;   // diagnostic: workgroups of the persistent launch (0 = resident slots)
 int g_gemm_persist = 0;        // 0 never (default: measured slower), 1 when a slot gets several tiles and nothing is split, 2 whenever eligible
 int g_gemm_split = 1;      // A/B knob: in-launch split-K of the forward / data-gradient GEMMs

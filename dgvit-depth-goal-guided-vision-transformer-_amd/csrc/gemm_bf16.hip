@@ -525,6 +525,22 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
         }
       };
       if (EPI == BEPI_DGELU_BF16) aux_fetch(0, auxv[0]);
+      // residual epilogue: the same look-ahead.  A load issued inside the piece loop makes every piece wait vmcnt(0) - the load
+      // AND the previous piece's store, one loaded-memory round trip per 16-byte piece, 32 pieces per thread and tile: the
+      // out-projection (K = 768: ~10 us of MFMA work per tile) spent most of its time there.  The residual of 16-row group g + 1 is
+      // requested piece by piece as group g consumes its own (4 NQ registers): a load is always older than the stores behind it.
+      const bool use_res = EPI == BEPI_F32 && p.res != nullptr;
+      fx4 resv[EPI == BEPI_F32 ? NQ : 1];
+      auto res_load = [&](int g, int q) -> fx4 {   // g = 2 i + half: one 16-row group of the wave's tile; q: its q-th row piece
+        const int ml = wr * WTM + g * 16 + q * RPI + erow, gm = m0 + ml;
+        const unsigned rr = p.res_mod > 0 ? (unsigned)(gm % p.res_mod) + 1u : (unsigned)ml;
+        const unsigned roff = (gm < p.M && ncol) ? (rr * (unsigned)p.ldr + coln) * 4u : DGVIT_BUF_OOB;
+        return __builtin_bit_cast(fx4, __builtin_amdgcn_raw_buffer_load_b128(rsX, roff, 0, 0));
+      };
+      if (use_res) {
+#pragma unroll
+        for (int q = 0; q < (EPI == BEPI_F32 ? NQ : 1); ++q) resv[q] = res_load(0, q);
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -553,10 +569,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
             const long long crow = p.c_rgrp > 0 ? gm + gm / p.c_rgrp + 1 : gm;
             const unsigned coff = ok ? ((unsigned)(crow - crow0) * (unsigned)p.ldc + coln) * CES : DGVIT_BUF_OOB;
             if (EPI == BEPI_F32 || EPI == BEPI_F32_PLAIN) {
-              if (EPI == BEPI_F32 && p.res) {
-                const unsigned rr = p.res_mod > 0 ? (unsigned)(gm % p.res_mod) + 1u : (unsigned)ml;
-                const unsigned roff = ok ? (rr * (unsigned)p.ldr + coln) * 4u : DGVIT_BUF_OOB;
-                v += __builtin_bit_cast(fx4, __builtin_amdgcn_raw_buffer_load_b128(rsX, roff, 0, 0));
+              if (use_res) {   // this piece's residual arrived a group ago; its register takes the next group's piece at once
+                v += resv[EPI == BEPI_F32 ? q : 0];
+                if (2 * i + half + 1 < 2 * MT) resv[EPI == BEPI_F32 ? q : 0] = res_load(2 * i + half + 1, q);
               }
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), rsC, coff, 0, 0);
             } else if (EPI == BEPI_BF16) {

@@ -182,13 +182,17 @@ void dgvit_set_gemm_split(int on);
 /* diagnostic: request `bytes` more dynamic LDS per fp32 GEMM workgroup than it uses (caps the workgroups per CU: occupancy probes) */
 void dgvit_set_gemm_lds_pad(int bytes);
 /* A/B knob: raise the wave priority (s_setprio 2) of the per-tile fp32 GEMM's main loop over the prologue / epilogue waves on
- * the same SIMD.  Default 0. */
+ * the same SIMD (bit 0).  Bits 1 and 2 are timing diagnostics (results are garbage; tools only): bit 1 - the kernel returns after the main loop
+ * WITHOUT writing C; bit 2 - every tile stores over tile 0 (the same instructions, no write stream to HBM).  Default 0. */
 void dgvit_set_gemm_loop_priority(int on);
-/* A/B knob: the persistent fp32 GEMM (tile loop inside the workgroup, next tile's fetch under the epilogue; NT / NN forms with
- * 16-byte-aligned operands).  mode 0 = never, 1 (default) = when a resident workgroup slot gets at least two tiles and no tile is
- * split, 2 = whenever the launch is eligible.  workgroups > 0 overrides the grid (diagnostic; 0 = resident slots).  Same results
- * bit for bit: the k order of a tile does not change. */
+/* The pipelined persistent fp32 GEMM (one k-tile stream per workgroup across its tiles, a tile's stores under the next tile's main
+ * loop; NT / NN forms, 16-byte-aligned operands, K = 16 k-tiles of the chosen tile: 256 at 16-deep, 512 at 32-deep k-tiles).
+ * mode 0 = never, 1 = when a resident workgroup slot gets at least two tiles and no tile is split, 2 = whenever the launch is
+ * eligible.  workgroups > 0 overrides the grid (diagnostic; 0 = automatic).  Same results bit for bit as the per-tile kernel: the
+ * k order of a tile does not change. */
 void dgvit_set_gemm_persistent(int mode, int workgroups);
+/* launches that took the pipelined kernel since the library was loaded (tests check that they exercise it) */
+long long dgvit_gemm_persistent_launches(void);
 /* diagnostic (tools/gemm_stamps.py): non-NULL = every fp32 GEMM launch writes 16 int64 per workgroup (< `workgroups`) into the
  * device buffer: [0..3] shader clock at kernel start / first k-tile in LDS / main loop done / stores issued, [7] stores drained (the
  * stamped run waits for them), [4] and [6] the 100 MHz counter at start and end, [5] HW_ID | XCC_ID << 32, [8 + 2c] / [9 + 2c] epilogue chunk c: C image in

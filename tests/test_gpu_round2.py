@@ -929,11 +929,11 @@ def test_attention_backward_single_pass_equals_two_phase(B, N, H, dh):
     (0, 0, 1000, 384, 256, 64128016, 8),       # NT, bias + residual, ragged M, tiles walk through several rounds per workgroup
     (0, 0, 1000, 384, 256, 64128016, 0),
     (0, 1, 777, 512, 256, 64128016, 16),       # NT, gelu2 (two outputs)
-    (0, 3, 520, 256, 144, 64064032, 8),        # NT, relu, K not a multiple of the k-tile
+    (0, 3, 520, 256, 512, 64064032, 8),        # NT, relu, 32-deep k-tiles
     (1, 0, 1000, 264, 512, 64064032, 8),       # NN plain, ragged N (multiple of 4, not of the tile)
     (1, 2, 900, 512, 256, 64128016, 24),       # NN, dgelu operand
-    (1, 4, 333, 128, 64, 64064016, 8),         # NN, drelu operand
-    (0, 0, 130, 128, 2048, 128128016, 2),      # big tile, long K
+    (1, 4, 333, 128, 512, 64064032, 8),        # NN, drelu operand, one MFMA column tile per wave
+    (0, 0, 300, 256, 256, 64128016, 2),        # two workgroups walk over all ten tiles
     (1, 2, 25600, 2048, 256, 0, 0),            # the C3 shapes themselves, automatic tile and grid
     (0, 1, 25600, 2048, 256, 0, 0),
 ])
@@ -964,7 +964,9 @@ def test_persistent_gemm_equals_per_tile_kernel(layout, epi, M, N, K, tile, wgs)
         return out if isinstance(out, tuple) else (out,)
 
     ref = run(0)
+    before = lib.dgvit_gemm_persistent_launches()
     got = run(2)
+    assert lib.dgvit_gemm_persistent_launches() == before + 1, "the launch did not take the pipelined kernel"
     for r, o in zip(ref, got):
         assert torch.isfinite(o).all()
         assert torch.equal(r, o), f"max diff {(r - o).abs().max().item()}"
@@ -978,6 +980,7 @@ def test_persistent_gemm_writes_nothing_outside_c():
     from dgvit_amd import _lib
     lib = dgvit_amd.load_library()
     M, N, K, ldc = 203, 132, 256, 160
+    lib.dgvit_set_gemm_tile(64128016)
     g = torch.Generator().manual_seed(5)
     A = torch.randn(M, K, generator=g).cuda()
     B = torch.randn(N, K, generator=g).cuda()
@@ -988,12 +991,15 @@ def test_persistent_gemm_writes_nothing_outside_c():
     nsc = lib.dgvit_gemm_scratch_floats(0, M, N, K)
     scratch = torch.zeros(max(nsc, 4), device="cuda")
     lib.dgvit_set_gemm_persistent(2, 3)
+    before = lib.dgvit_gemm_persistent_launches()
     try:
         rc = lib.dgvit_gemm(0, 0, A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), ldc, M, N, K, bias.data_ptr(), None, 0, None, 0, None, 0,
                             scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream)
     finally:
         lib.dgvit_set_gemm_persistent(0, 0)
+        lib.dgvit_set_gemm_tile(0)
     _lib.check(rc, "dgvit_gemm")
+    assert lib.dgvit_gemm_persistent_launches() == before + 1
     torch.cuda.synchronize()
     ref = (A.double() @ B.double().t() + bias.double()).float()
     torch.testing.assert_close(C[:, :N], ref, atol=2e-4, rtol=1e-5)
