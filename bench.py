@@ -394,12 +394,11 @@ def main():
 
         traffic = None
         try:   # HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (tools/pmc_traffic.py)
-            tpath = os.path.join(ROOT, "profiles", "r02_a_hbm_traffic.json")
-            if not os.path.exists(tpath):
-                tpath = os.path.join(ROOT, "profiles", "r01_m_hbm_traffic.json")
+            import glob
+            tpath = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))[-1]   # the latest round's passes
             with open(tpath) as f:
                 traffic = json.load(f)["kernels"]["gemm_f32_kernel"]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, IndexError):
             tpath = None
         out = {
             "metric": "depth frames/sec through DGViT fwd+bwd, batch 512x84x84",
