@@ -67,7 +67,7 @@ struct GemmParams {
   long long slab_capacity; int counter_capacity;   // floats / ints available behind `slabs` / `counters`
   int split_from, nsplit, kchunk_split;            // filled in at launch
   long long* stamps; int stamp_capacity;           // diagnostic (dgvit_set_gemm_stamps): 16 counters per workgroup, or null
-  int loop_prio;                                   // A/B knob (dgvit_set_gemm_loop_priority)
+  int diag;                                        // A/B knob (dgvit_set_gemm_diagnostics)
 };
 
 struct GemmSplitPlan {

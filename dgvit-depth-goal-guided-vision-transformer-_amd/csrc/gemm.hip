@@ -37,7 +37,7 @@ extern int g_gemm_lds_pad;
 extern int g_gemm_persist;
 extern int g_gemm_persist_grid;
 extern long long g_gemm_persist_launches;
-extern int g_gemm_loop_prio;
+extern int g_gemm_diag;
 extern long long* g_gemm_stamps;
 extern int g_gemm_stamp_capacity;
 
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
     }
     __syncthreads();
     stamp(p, 1, tid);
-    if (p.loop_prio & 1) __builtin_amdgcn_s_setprio(2);   // A/B knob: main-loop waves ahead of the prologue / epilogue waves they share a SIMD with
+    if (p.diag & 1) __builtin_amdgcn_s_setprio(2);   // A/B knob: main-loop waves ahead of the prologue / epilogue waves they share a SIMD with
     for (int kt = 0; kt < nk; ++kt) {
       const float* la = smem + (kt & 1) * STAGE;
       const float* lb = la + A_TILE;
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
       }
       __syncthreads();
     }
-    if (p.loop_prio & 1) __builtin_amdgcn_s_setprio(0);
+    if (p.diag & 1) __builtin_amdgcn_s_setprio(0);
   } else {
     FA::run(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
     FB::run(rb, p.B, p.ldb, n0, p.N, kbeg, kend, tid);
@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   }
 
   stamp(p, 2, tid);
-  if (p.loop_prio & 2) {   // diagnostic (dgvit_set_gemm_loop_priority(2)): main loop only - what would a free epilogue be worth?
+  if (p.diag & 2) {   // diagnostic (dgvit_set_gemm_diagnostics(2)): main loop only - what would a free epilogue be worth?
     float sacc = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -642,7 +642,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
           long long crow = m;
           if (EPI == EPI_STORE && p.c_rgrp > 0) crow = (long long)m + m / p.c_rgrp + 1;
           int ncol = n;
-          if (p.loop_prio & 4) {   // diagnostic: every tile stores over tile 0 (the same instructions, no HBM write stream; results garbage)
+          if (p.diag & 4) {   // diagnostic: every tile stores over tile 0 (the same instructions, no HBM write stream; results garbage)
             crow = m - m0;
             ncol = cc;
           }
@@ -774,7 +774,7 @@ __global__ void __launch_bounds__(256) reduce_slabs_scalar_kernel(const float* _
 
 // ---- pipelined persistent variant: one continuous k-tile stream per workgroup, a tile's stores under the next tile's MFMAs -----
 // What the per-tile kernel loses at the K = 256 shapes (45 % of the step's GEMM time) is its epilogue: with the stores skipped
-// (diagnostic bit of dgvit_set_gemm_loop_priority) QKV / fc1 / fc2-dgrad run at 133-135 TFLOP/s instead of 101-107
+// (diagnostic bit of dgvit_set_gemm_diagnostics) QKV / fc1 / fc2-dgrad run at 133-135 TFLOP/s instead of 101-107
 // (profiles/r02_c_gemm_no_epilogue_bound.txt).  Shortening the epilogue did not help (the time reappears as waiting elsewhere), and
 // a persistent tile loop that keeps epilogue and main loop as separate phases is slower still: all workgroups of the chip fall into
 // step and store at the same moment (profiles/r02_c_gemm_persistent_kernel_negative_result.txt).  So here there are no phases:
@@ -1163,7 +1163,7 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
   GemmParams p = p0;
   p.stamps = g_gemm_stamps;
   p.stamp_capacity = g_gemm_stamp_capacity;
-  p.loop_prio = g_gemm_loop_prio;
+  p.diag = g_gemm_diag;
   const long long tiles = (long long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   DGVIT_CHECK_ARG(tiles > 0 && tiles < (1ll << 31), "gemm: bad tile count %lld", tiles);
   long long blocks = tiles;
@@ -1231,7 +1231,7 @@ int g_gemm_tile_hint = 0;  // test/bench override: 0 auto, 64, 128
 int g_gemm_lds_pad = 0;    // diagnostic: extra dynamic LDS bytes per workgroup (caps the workgroups per CU: occupancy probe)
 long long* g_gemm_stamps = nullptr;   // diagnostic: per-workgroup clock stamps of the next launches (tools/gemm_stamps.py)
 int g_gemm_stamp_capacity = 0;
-int g_gemm_loop_prio = 0;      // A/B knob: s_setprio 2 around the main loop of the per-tile kernel
+int g_gemm_diag = 0;      // A/B knob: s_setprio 2 around the main loop of the per-tile kernel
 long long g_gemm_persist_launches = 0;   // launches that took the pipelined kernel (tests check that they exercise it)
 int g_gemm_persist_grid = 0;   // diagnostic: workgroups of the persistent launch (0 = resident slots)
 int g_gemm_persist = 0;        // 0 never (default: measured slower), 1 when a slot gets several tiles and nothing is split, 2 whenever eligible

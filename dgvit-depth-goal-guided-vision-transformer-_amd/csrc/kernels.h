@@ -39,7 +39,7 @@ extern int g_gemm_split;
 extern int g_gemm_lds_pad;
 extern int g_gemm_persist;
 extern long long g_gemm_persist_launches;
-extern int g_gemm_loop_prio;
+extern int g_gemm_diag;
 extern int g_gemm_persist_grid;
 extern long long* g_gemm_stamps;
 extern int g_gemm_stamp_capacity;

@@ -181,10 +181,11 @@ void dgvit_set_grouped_reduce(int on);
 void dgvit_set_gemm_split(int on);
 /* diagnostic: request `bytes` more dynamic LDS per fp32 GEMM workgroup than it uses (caps the workgroups per CU: occupancy probes) */
 void dgvit_set_gemm_lds_pad(int bytes);
-/* A/B knob: raise the wave priority (s_setprio 2) of the per-tile fp32 GEMM's main loop over the prologue / epilogue waves on
- * the same SIMD (bit 0).  Bits 1 and 2 are timing diagnostics (results are garbage; tools only): bit 1 - the kernel returns after the main loop
- * WITHOUT writing C; bit 2 - every tile stores over tile 0 (the same instructions, no write stream to HBM).  Default 0. */
-void dgvit_set_gemm_loop_priority(int on);
+/* Diagnostics of the per-tile fp32 GEMM (tools only; default 0).  Bit 0: A/B knob, raise the wave priority (s_setprio 2) of the main
+ * loop over the prologue / epilogue waves on the same SIMD (measured: no effect).  Bits 1 and 2 are TIMING diagnostics whose results are
+ * garbage: bit 1 - the kernel returns after the main loop without writing C; bit 2 - every tile stores over tile 0 (the same epilogue
+ * instructions and side reads, no write stream to HBM).  DESIGN.md 3.9 uses them to take the epilogue's cost apart. */
+void dgvit_set_gemm_diagnostics(int bits);
 /* The pipelined persistent fp32 GEMM (one k-tile stream per workgroup across its tiles, a tile's stores under the next tile's main
  * loop; NT / NN forms, 16-byte-aligned operands, K = 16 k-tiles of the chosen tile: 256 at 16-deep, 512 at 32-deep k-tiles).
  * mode 0 = never, 1 = when a resident workgroup slot gets at least two tiles and no tile is split, 2 = whenever the launch is

@@ -9,8 +9,8 @@ from dgvit_amd import functional as F
 lib = dgvit_amd.load_library()
 if "PERSIST" in os.environ:
     lib.dgvit_set_gemm_persistent(int(os.environ["PERSIST"]), int(os.environ.get("PGRID", 0)))
-if "LOOPPRIO" in os.environ:
-    lib.dgvit_set_gemm_loop_priority(int(os.environ["LOOPPRIO"]))
+if "GEMMDIAG" in os.environ:
+    lib.dgvit_set_gemm_diagnostics(int(os.environ["GEMMDIAG"]))
 MS = [int(x) for x in os.environ["MS"].split(",")] if "MS" in os.environ else (8192, 12288, 16384, 20480, 24576, 25600, 28672, 32768, 65536)
 dev = "cuda"
 
