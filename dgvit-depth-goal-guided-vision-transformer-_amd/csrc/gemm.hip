@@ -69,6 +69,7 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // branch-free and can be scheduled among the MFMAs.  VEC == 1: scalar loads with explicit predicates
 // (odd leading dimensions / unaligned bases; small head and odd-patch GEMMs only).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define DGVIT_OOB 0xFFFFFFF0u
 
 template <int R, int BK, bool KC, int VEC, int NT, bool GATHER = false>
@@ -345,11 +346,26 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   const int n = n0 + cc;
   // The bias row piece is fetched BEFORE the main loop (4 registers): at the epilogue it would be a dependent round trip of
   // several thousand cycles under load, paid by every tile.
+  // which epilogue (uniform over the launch except for split tiles): see "direct epilogue" below
+  constexpr bool DIRECT_OK = LAYOUT != GEMM_TN && VEC == 4 && !GATHER && EPI != EPI_SPLITK && (BKC || TN <= 2);
+  const bool direct = DIRECT_OK && nz == 1 && p.evec && p.c_rgrp == 0 && p.res_mod == 0 && (EPI != EPI_GELU2 || p.ldc2 == p.ldc) && !(p.diag & 8);
+  int dcol[TN];     // direct epilogue: this lane's column(s) inside the tile
+  float dbias[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    dcol[j] = wn * WN + (BKC ? j * 32 + li : li * TN + j);
+    dbias[j] = 0.f;
+  }
   float bias4[4] = {0.f, 0.f, 0.f, 0.f};
   if ((EPI == EPI_STORE || EPI == EPI_GELU2 || EPI == EPI_RELU) && p.bias) {
+    if (direct) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (n + e < p.N) bias4[e] = p.bias[n + e];
+      for (int j = 0; j < TN; ++j) dbias[j] = p.bias[min(n0 + dcol[j], p.N - 1)];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < p.N) bias4[e] = p.bias[n + e];
+    }
   }
 
   // LDS -> fragments of one 8-deep k-group; MFMAs of one k-group
@@ -472,6 +488,93 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
         for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
     if (sacc == 1.2345678e33f) p.C[0] = sacc;
     return;
+  }
+  // ---- direct epilogue (NT / NN forms, whole-K tiles, vector-aligned outputs, plain row mapping) ---------------------------------
+  // The accumulators go to global memory straight from registers: a lane's 4-byte (NT: one column per MFMA tile) or 8-byte (NN: its
+  // two adjacent columns) pieces, 128 / 256 contiguous bytes per half-wave, through a buffer descriptor whose range check drops the
+  // rows past M (columns past N get an out-of-range offset) - no LDS image, no barrier, no branch.  Side inputs (residual /
+  // activation-gradient operand) of the whole wave tile are requested first and folded in before the first store.  Against the LDS
+  // image path below (kept for split tiles, the row-remapped patch embedding and unaligned callers): QKV 113 -> 116-122 TFLOP/s.
+  if constexpr (DIRECT_OK) {
+    if (direct) {
+      constexpr int CW = BKC ? 1 : TN;
+      auto tile_rsrc = [&](const float* base, int ld) {
+        long long bytes = ((long long)(p.M - 1 - m0) * ld + (p.N - n0)) * 4;   // tile origin .. end of the matrix
+        if (bytes > 0x7FFFFFFFll) bytes = 0x7FFFFFFFll;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + (long long)m0 * ld + n0), 0, (int)bytes, 0x00020000);
+      };
+      // byte offset of accumulator element r of MFMA tile (i, j) in that window; everything in the VGPR operand (the scalar offset of
+      // a buffer instruction is not range-checked)
+      auto eoff = [&](int i, int j, int r, int ld) -> unsigned {
+        const unsigned rowpart = (unsigned)((wm * WM + i * 32 + (r & 3) + 8 * (r >> 2)) * ld * 4);   // uniform
+        return n0 + dcol[j] < p.N ? rowpart + (unsigned)((4 * h * ld + dcol[j]) * 4) : DGVIT_OOB;
+      };
+      constexpr bool HAS_SIDE = EPI == EPI_STORE || EPI == EPI_DGELU || EPI == EPI_DRELU;
+      const bool use_side = HAS_SIDE && (EPI == EPI_STORE ? p.res != nullptr : true);
+      if (HAS_SIDE && use_side) {
+        const float* sb = EPI == EPI_STORE ? p.res : p.aux;
+        const int sld = EPI == EPI_STORE ? p.ldr : p.ldaux;
+        const __amdgpu_buffer_rsrc_t sr = tile_rsrc(sb, sld);
+        float side[TM][16][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)   // (32-bit loads: this toolchain narrows a b64 buffer load whose halves are bit-cast to float)
+              side[i][r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, eoff(i, j, r, sld), 0, 0));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float sv = side[i][r][j];
+              if (EPI == EPI_STORE) acc[i][j][r] += sv;                     // residual first, bias below: the order of the LDS path
+              else if (EPI == EPI_DGELU) acc[i][j][r] *= gelu_erf_grad(sv);
+              else acc[i][j][r] = sv > 0.f ? acc[i][j][r] : 0.f;
+            }
+      }
+      const __amdgpu_buffer_rsrc_t cr = tile_rsrc(p.C, p.ldc);
+      __amdgpu_buffer_rsrc_t c2r = cr;
+      if (EPI == EPI_GELU2) c2r = tile_rsrc(p.C2, p.ldc2);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v[TN];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            v[j] = acc[i][j][r];
+            if (EPI == EPI_STORE || EPI == EPI_GELU2) v[j] += dbias[j];
+            else if (EPI == EPI_RELU) v[j] = fmaxf(v[j] + dbias[j], 0.f);
+          }
+          if constexpr (CW == 1) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), cr, eoff(i, j, r, p.ldc), 0, 0);
+              if (EPI == EPI_GELU2)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gelu_erf(v[j])), c2r, eoff(i, j, r, p.ldc), 0, 0);
+            }
+          } else {
+            u32x2 w;
+            w[0] = __builtin_bit_cast(unsigned, v[0]);
+            w[1] = __builtin_bit_cast(unsigned, v[1]);
+            __builtin_amdgcn_raw_buffer_store_b64(w, cr, eoff(i, 0, r, p.ldc), 0, 0);
+            if (EPI == EPI_GELU2) {
+              w[0] = __builtin_bit_cast(unsigned, gelu_erf(v[0]));
+              w[1] = __builtin_bit_cast(unsigned, gelu_erf(v[1]));
+              __builtin_amdgcn_raw_buffer_store_b64(w, c2r, eoff(i, 0, r, p.ldc), 0, 0);
+            }
+          }
+        }
+      stamp(p, 3, tid);
+      if (p.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(p, 7, tid);
+      }
+      return;
+    }
   }
   // ---- epilogue ------------------------------------------------------------------------------------
   float* Cz = p.C;
@@ -790,8 +893,6 @@ __global__ void __launch_bounds__(256) reduce_slabs_scalar_kernel(const float* _
 // fully unrolled, which is what gives every iteration ITS accumulator registers to drain.  Memory operations of one iteration, in
 // program order: operand fetch, side-input request, stores - vmcnt retires in order on gfx9, so every wait the compiler needs is for
 // something older than the stores around it.  64 accumulator registers: 4 workgroups per CU instead of 5.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-
 template <class T, int LAYOUT, int EPI, int NK>
 __global__ void __launch_bounds__(T::NT, T::LDS_BYTES * 4 <= 160 * 1024 ? 4 : 2) gemm_f32_pipe_kernel(const GemmParams p) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NT;

@@ -184,7 +184,8 @@ void dgvit_set_gemm_lds_pad(int bytes);
 /* Diagnostics of the per-tile fp32 GEMM (tools only; default 0).  Bit 0: A/B knob, raise the wave priority (s_setprio 2) of the main
  * loop over the prologue / epilogue waves on the same SIMD (measured: no effect).  Bits 1 and 2 are TIMING diagnostics whose results are
  * garbage: bit 1 - the kernel returns after the main loop without writing C; bit 2 - every tile stores over tile 0 (the same epilogue
- * instructions and side reads, no write stream to HBM).  DESIGN.md 3.9 uses them to take the epilogue's cost apart. */
+ * instructions and side reads, no write stream to HBM; LDS-image epilogue only).  Bit 3: A/B knob, use the LDS-image epilogue where the
+ * direct (register) epilogue would be taken.  DESIGN.md 3.9 uses them to take the epilogue's cost apart. */
 void dgvit_set_gemm_diagnostics(int bits);
 /* The pipelined persistent fp32 GEMM (one k-tile stream per workgroup across its tiles, a tile's stores under the next tile's main
  * loop; NT / NN forms, 16-byte-aligned operands, K = 16 k-tiles of the chosen tile: 256 at 16-deep, 512 at 32-deep k-tiles).

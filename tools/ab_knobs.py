@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B of library knobs on the C3 training step in ONE process (boxes differ by several %, so A/B across gpurun
-calls says nothing): python tools/ab_knobs.py grouped_reduce|wgrad_overlap [rounds]"""
+calls says nothing): python tools/ab_knobs.py grouped_reduce|wgrad_overlap|gemm_diagnostics [rounds] [value of the 1-arm]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +9,7 @@ from dgvit_amd.optim import FlatAdam
 lib = dgvit_amd.load_library()
 knob = sys.argv[1] if len(sys.argv) > 1 else "grouped_reduce"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+on_value = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # value passed for the "1" arm (bit masks: gemm_diagnostics 8 = LDS-image epilogue)
 setter = getattr(lib, "dgvit_set_" + knob)
 dev = torch.device("cuda")
 torch.manual_seed(3407)
@@ -28,7 +29,7 @@ def step():
 res = {0: [], 1: []}
 for r in range(rounds):
     for v in (0, 1):
-        setter(v)
+        setter(on_value if v else 0)
         for _ in range(3):
             step()
         torch.cuda.synchronize()
