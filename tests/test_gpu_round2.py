@@ -1005,3 +1005,58 @@ def test_persistent_gemm_writes_nothing_outside_c():
     torch.testing.assert_close(C[:, :N], ref, atol=2e-4, rtol=1e-5)
     assert (C[:, N:] == 777.0).all(), "columns between N and ldc were written"
     assert (buf[:pad] == 777.0).all() and (buf[pad + M * ldc:] == 777.0).all(), "wrote outside C"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout,epi,M,N,K,ldc", [(0, 0, 203, 132, 256, 160), (0, 1, 77, 260, 64, 264), (1, 2, 130, 136, 96, 200), (1, 0, 65, 68, 512, 68)])
+def test_direct_gemm_epilogue_stays_inside_c(layout, epi, M, N, K, ldc):
+    """The direct (register) epilogue of the per-tile fp32 GEMM - the default for the NT / NN forms - writes through a range-checked
+    buffer descriptor: a C window with ldc >= N inside a canary buffer keeps its padding columns, the rows past M and everything
+    around it; the values equal an fp64 reference and the LDS-image epilogue (dgvit_set_gemm_diagnostics(8))."""
+    import math
+    import dgvit_amd
+    from dgvit_amd import _lib
+    lib = dgvit_amd.load_library()
+    g = torch.Generator().manual_seed(M * 3 + N)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn(N, K, generator=g) if layout == 0 else torch.randn(K, N, generator=g)).cuda()
+    bias = torch.randn(N, generator=g).cuda() if layout == 0 else None
+    res = torch.randn(M, N, generator=g).cuda() if (layout == 0 and epi == 0) else None
+    aux = torch.randn(M, N, generator=g).cuda() if epi == 2 else None
+    pad = 2048
+    nsc = lib.dgvit_gemm_scratch_floats(layout, M, N, K)
+    scratch = torch.zeros(max(nsc, 4), device="cuda")
+    outs = []
+    for diag in (0, 8):
+        buf = torch.full((pad + M * ldc + pad,), 555.0, device="cuda")
+        buf2 = torch.full((pad + M * ldc + pad,), 555.0, device="cuda")
+        C, C2 = buf[pad:pad + M * ldc].view(M, ldc), buf2[pad:pad + M * ldc].view(M, ldc)
+        lib.dgvit_set_gemm_diagnostics(diag)
+        lib.dgvit_set_gemm_split(0)
+        try:
+            rc = lib.dgvit_gemm(layout, epi, A.data_ptr(), K, B.data_ptr(), K if layout == 0 else N, C.data_ptr(), ldc, M, N, K,
+                                bias.data_ptr() if bias is not None else None, res.data_ptr() if res is not None else None, N,
+                                C2.data_ptr() if epi == 1 else None, ldc, aux.data_ptr() if aux is not None else None, N,
+                                scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream)
+        finally:
+            lib.dgvit_set_gemm_diagnostics(0)
+            lib.dgvit_set_gemm_split(1)
+        _lib.check(rc, "dgvit_gemm")
+        torch.cuda.synchronize()
+        for b_, c_ in ((buf, C),) + (((buf2, C2),) if epi == 1 else ()):
+            assert (c_[:, N:] == 555.0).all(), "columns between N and ldc were written"
+            assert (b_[:pad] == 555.0).all() and (b_[pad + M * ldc:] == 555.0).all(), "wrote outside C"
+        outs.append((C[:, :N].clone(), C2[:, :N].clone()))
+    acc = A.double() @ (B.double().t() if layout == 0 else B.double())
+    if epi == 0:
+        ref = acc + (bias.double() if bias is not None else 0) + (res.double() if res is not None else 0)
+    elif epi == 1:
+        ref = acc + bias.double()
+    else:
+        x = aux.double()
+        ref = acc * (0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-x * x / 2) / math.sqrt(2 * math.pi))
+    torch.testing.assert_close(outs[0][0], ref.float(), atol=3e-4, rtol=1e-5)
+    assert torch.equal(outs[0][0], outs[1][0]), "direct and LDS-image epilogues differ"
+    if epi == 1:
+        torch.testing.assert_close(outs[0][1], torch.nn.functional.gelu(ref).float(), atol=3e-4, rtol=1e-5)
+        assert torch.equal(outs[0][1], outs[1][1])
