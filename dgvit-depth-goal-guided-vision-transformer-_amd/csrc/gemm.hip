@@ -519,10 +519,21 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
+          for (int r = 0; r < 16; ++r) {
+            if constexpr (CW == 2) {
+              // one 8-byte load for the lane's two adjacent columns.  The result is bit-cast as a WHOLE vector: casting the two
+              // dwords to float one by one is what this toolchain narrows to a one-dword load (the equality tests
+              // against the LDS-image epilogue and the pipelined kernel, which use 4-byte loads, would catch it)
+              typedef float f32x2v __attribute__((ext_vector_type(2)));
+              const f32x2v v2 = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(sr, eoff(i, 0, r, sld), 0, 0));
+              side[i][r][0] = v2[0];
+              side[i][r][1] = v2[1];
+            } else {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)   // (32-bit loads: this toolchain narrows a b64 buffer load whose halves are bit-cast to float)
-              side[i][r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, eoff(i, j, r, sld), 0, 0));
+              for (int j = 0; j < TN; ++j)
+                side[i][r][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, eoff(i, j, r, sld), 0, 0));
+            }
+          }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
