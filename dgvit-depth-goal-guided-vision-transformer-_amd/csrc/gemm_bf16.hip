@@ -722,6 +722,7 @@ int dispatch(const GemmBf16Params& p, hipStream_t st) {
     case 256256: return launch<BTile<256, 256, 2, 4>, EPI, true>(p, st);
     case 256128: return launch<BTile<256, 128, 4, 2>, EPI, true>(p, st);
     case 128128: return launch<BTile<128, 128, 2, 2>, EPI, false>(p, st);
+    case 256254: return launch<BTile<256, 256, 2, 2>, EPI, false>(p, st);   // experiment: 4 waves of 128 x 128 (one per SIMD), per-tile kernel
     default: return dgvit_set_error(DGVIT_ERR_ARG, "gemm_bf16: unknown tile %d", tile);
   }
 }

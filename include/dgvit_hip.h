@@ -337,7 +337,8 @@ int dgvit_cast_f32_bf16(const float* src, unsigned short* dst, long long n, void
 int dgvit_gemm_bf16(int epilogue, const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, int M,
                     int N, int K, const float* bias, const float* res, int ldr, unsigned short* C2, int ldc2,
                     const unsigned short* aux, int ldaux, void* stream);
-/* test/bench knob: force the bf16 GEMM workgroup tile (0 = automatic; 256256, 256128, 128128) */
+/* test/bench knob: force the bf16 GEMM workgroup tile (0 = automatic; 256256, 256128, 128128; 256254 = probe: per-tile kernel with
+ * 4 waves of 128 x 128, profiles/r02_e_bf16_gemm_4wave_128x128_probe.txt) */
 void dgvit_set_gemm_bf16_tile(int tile);
 /* test/bench knob: row panels per walk group of the persistent bf16 GEMM's tile order (default 8) */
 void dgvit_set_gemm_bf16_group_m(int rows);

@@ -19,8 +19,8 @@ template <int KIND>   // 0: v_mfma_f32_32x32x2_f32   1: v_mfma_f32_32x32x16_bf16
                       // 4: as 3, operands re-read from LDS at the fp32 GEMM's rate (3 ds_read_b128 per 8 MFMAs)
                       // 5: as 4 plus the GEMM's LDS write and global (L2-resident) read traffic: 1.5 b128 loads + ds_writes per 8 MFMAs
 __global__ void __launch_bounds__(256) probe(long long* out, float* sink, int iters, const float4* __restrict__ gsrc) {
-  __shared__ float lds[8192 + 4096];
-  for (int i = threadIdx.x; i < 8192 + 4096; i += 256) lds[i] = (float)((i * 2654435761u) >> 9) * (1.0f / 4194304.0f) - 1.0f;
+  __shared__ float lds[4096 + 2048];   // 24 KB: up to 6 workgroups per CU
+  for (int i = threadIdx.x; i < 4096 + 2048; i += 256) lds[i] = (float)((i * 2654435761u) >> 9) * (1.0f / 4194304.0f) - 1.0f;
   __syncthreads();
   f32x16 a0, a1, a2, a3;
   for (int r = 0; r < 16; ++r) a0[r] = a1[r] = a2[r] = a3[r] = 0.f;
@@ -52,14 +52,14 @@ __global__ void __launch_bounds__(256) probe(long long* out, float* sink, int it
       a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx, by, a2, 0, 0, 0);
       a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx, by, a3, 0, 0, 0);
     } else if (KIND == 4 || KIND == 5) {
-      const float4 qa = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + (i & 7) * 1040) & 8188));
-      const float4 qb = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + 4160 + (i & 7) * 1040) & 8188));
-      const float4 qc = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + 2080 + (i & 7) * 1040) & 8188));
+      const float4 qa = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + (i & 7) * 1040) & 4092));
+      const float4 qb = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + 2080 + (i & 7) * 1040) & 4092));
+      const float4 qc = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + 1040 + (i & 7) * 1040) & 4092));
       if (KIND == 5) {
         const float4 g0 = gsrc[(threadIdx.x + (i & 1023) * 256 + blockIdx.x * 64) & 0x3FFFF];
         float4 g1 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i & 1) g1 = gsrc[(threadIdx.x + (i & 1023) * 256 + blockIdx.x * 64 + 131072) & 0x3FFFF];
-        *reinterpret_cast<float4*>(lds + 8192 + ((threadIdx.x * 4 + (i & 3) * 1024) & 4092)) = make_float4(g0.x + g1.x, g0.y + g1.y, g0.z, g0.w);
+        *reinterpret_cast<float4*>(lds + 4096 + ((threadIdx.x * 4 + (i & 1) * 1024) & 2044)) = make_float4(g0.x + g1.x, g0.y + g1.y, g0.z, g0.w);
       }
       a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, qb.x, a0, 0, 0, 0);
       a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, qc.x, a1, 0, 0, 0);
@@ -73,9 +73,9 @@ __global__ void __launch_bounds__(256) probe(long long* out, float* sink, int it
       // v_mfma_f32_16x16x4_f32 (8 passes, 4 accumulator registers): the same FLOPs per cycle with half the accumulator traffic
       float4 qa, qb, qc;
       if (KIND == 7) {
-        qa = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + (i & 7) * 1040) & 8188));
-        qb = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + 4160 + (i & 7) * 1040) & 8188));
-        qc = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + 2080 + (i & 7) * 1040) & 8188));
+        qa = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + (i & 7) * 1040) & 4092));
+        qb = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + 2080 + (i & 7) * 1040) & 4092));
+        qc = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + 1040 + (i & 7) * 1040) & 4092));
       } else {
         qa = make_float4(rx[0], rx[1], rx[2], rx[3]); qb = make_float4(ry[0], ry[1], ry[2], ry[3]); qc = make_float4(ry[4], ry[5], ry[6], ry[7]);
       }
