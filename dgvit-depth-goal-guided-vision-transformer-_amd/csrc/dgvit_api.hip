@@ -264,6 +264,8 @@ extern "C" void dgvit_set_gemm_tile(int tile) { g_gemm_tile_hint = tile; }
 extern "C" void dgvit_set_prune_last_layer(int on) { g_prune_last = on ? 1 : 0; }
 extern "C" void dgvit_set_wgrad_overlap(int on) { g_overlap_wgrad = on ? 1 : 0; }
 extern "C" void dgvit_set_grouped_reduce(int on) { g_group_reduce = on ? 1 : 0; }
+static int g_ln_fusion = 1;
+extern "C" void dgvit_set_ln_fusion(int on) { g_ln_fusion = on ? 1 : 0; }
 extern "C" void dgvit_set_gemm_split(int on) { g_gemm_split = on ? 1 : 0; }
 extern "C" void dgvit_set_gemm_stamps(long long* stamps, int workgroups) {
   g_gemm_stamps = stamps;
@@ -393,6 +395,7 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
   if (!save && g_small_path && !d.pool_mean && d.T <= g_small_path_max_rows && frame_path_supports(d.B, d.N, d.D, d.H, d.dh, d.M))
     return frame_path_forward(x, params, d.L, ws + w.layer0, feat, d.B, d.N, d.D, d.H, d.dh, d.M, st);
 
+  const bool ln_fused = g_ln_fusion && d.D == 64 && g_gemm_tile_hint == 0;   // (the automatic tile for N = 64 is 64 wide)
   for (int i = 0; i < d.L; ++i) {
     const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
     float* lb = ws + w.layer0 + w.layer_stride * i;
@@ -403,7 +406,11 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     const bool last = g_prune_last && !d.pool_mean && i == d.L - 1;
     const int tok = last ? d.B : T, rs = last ? d.N : 1;
     // x = attn(LN(x)) + x   (GoalFormer.py:103, 36-37, 71-82)
-    TRY(layernorm_fwd(x, lp[L_LN1W], lp[L_LN1B], lb + w.ln1, lb + w.mean1, lb + w.rstd1, T, d.D, 1e-5f, 1, st));
+    // D <= 64 (the shipped model): a 64-wide GEMM tile holds whole rows of the residual stream, so each LayerNorm runs inside the
+    // epilogue of the GEMM that produces its input (to_out -> LN2, fc2 -> the next block's LN1; bit-identical to the LayerNorm
+    // kernel).  Only the first block's LN1 is a launch of its own: 8 -> 1 LayerNorm launches in the shipped 4-block encoder.
+    if (!(ln_fused && i > 0))
+      TRY(layernorm_fwd(x, lp[L_LN1W], lp[L_LN1B], lb + w.ln1, lb + w.mean1, lb + w.rstd1, T, d.D, 1e-5f, 1, st));
     if (!last) {
       GemmParams p = gp(lb + w.ln1, d.D, lp[L_QKV], d.D, lb + w.qkv, 3 * d.I, T, 3 * d.I, d.D);
       sk.attach(p);
@@ -420,11 +427,15 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     {
       GemmParams p = gp(lb + w.ao, rs * d.I, lp[L_OUTW], d.I, lb + w.xmid, rs * d.D, tok, d.D, d.I);
       p.bias = lp[L_OUTB]; p.res = x; p.ldr = rs * d.D;
+      if (ln_fused) {
+        p.ln_g = lp[L_LN2W]; p.ln_b = lp[L_LN2B]; p.ln_y = lb + w.ln2; p.ln_ld = (long long)rs * d.D;
+        p.ln_mean = lb + w.mean2; p.ln_rstd = lb + w.rstd2; p.ln_eps = 1e-5f;
+      }
       sk.attach(p);
       TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
     }
     // x = ff(LN(x)) + x     (GoalFormer.py:104, 42-50)
-    TRY(layernorm_fwd(lb + w.xmid, lp[L_LN2W], lp[L_LN2B], lb + w.ln2, lb + w.mean2, lb + w.rstd2, tok, d.D, 1e-5f, rs, st));
+    if (!ln_fused) TRY(layernorm_fwd(lb + w.xmid, lp[L_LN2W], lp[L_LN2B], lb + w.ln2, lb + w.mean2, lb + w.rstd2, tok, d.D, 1e-5f, rs, st));
     {
       GemmParams p = gp(lb + w.ln2, rs * d.D, lp[L_FC1W], d.D, lb + w.h1, d.M, tok, d.M, d.D);   // h1 / a1 are dense (tok, M)
       p.bias = lp[L_FC1B]; p.C2 = lb + w.a1; p.ldc2 = d.M;
@@ -434,6 +445,12 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     {
       GemmParams p = gp(lb + w.a1, d.M, lp[L_FC2W], d.M, xo, rs * d.D, tok, d.D, d.M);
       p.bias = lp[L_FC2B]; p.res = lb + w.xmid; p.ldr = rs * d.D;
+      if (ln_fused && i + 1 < d.L) {   // the next block's LN1 (this block is never the pruned last one: all T rows)
+        const float* const* ln = params + P_L0 + DGVIT_PARAMS_PER_LAYER * (i + 1);
+        float* nb = ws + w.layer0 + w.layer_stride * (i + 1);
+        p.ln_g = ln[L_LN1W]; p.ln_b = ln[L_LN1B]; p.ln_y = nb + w.ln1; p.ln_ld = d.D;
+        p.ln_mean = nb + w.mean1; p.ln_rstd = nb + w.rstd1; p.ln_eps = 1e-5f;
+      }
       sk.attach(p);
       TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
     }

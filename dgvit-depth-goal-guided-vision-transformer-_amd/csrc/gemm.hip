@@ -348,7 +348,8 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   // several thousand cycles under load, paid by every tile.
   // which epilogue (uniform over the launch except for split tiles): see "direct epilogue" below
   constexpr bool DIRECT_OK = LAYOUT != GEMM_TN && VEC == 4 && !GATHER && EPI != EPI_SPLITK && (BKC || TN <= 2);
-  const bool direct = DIRECT_OK && nz == 1 && p.evec && p.c_rgrp == 0 && p.res_mod == 0 && (EPI != EPI_GELU2 || p.ldc2 == p.ldc) && !(p.diag & 8);
+  const bool direct = DIRECT_OK && nz == 1 && p.evec && p.c_rgrp == 0 && p.res_mod == 0 && (EPI != EPI_GELU2 || p.ldc2 == p.ldc) && !(p.diag & 8) &&
+                      !p.ln_y;   // (the fused LayerNorm reduces over the 16 lanes that hold a row of the LDS image)
   int dcol[TN];     // direct epilogue: this lane's column(s) inside the tile
   float dbias[TN];
 #pragma unroll
@@ -593,6 +594,29 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
     Cz += (long long)blockIdx.z * p.slab_stride;
     if (p.colsum && n0 == 0 && tid < BM && m0 + tid < p.M) Cz[(long long)p.M * p.N + m0 + tid] = bsum;
   }
+  // Fused LayerNorm of a finished output row (p.ln_y; launch checks N == BN, so the BN / 4 lanes tid % C4 of a wave hold the row).
+  // The arithmetic and its order are those of layernorm_fwd_kernel (float4 partial sums, xor butterfly; the butterfly steps that kernel
+  // takes over lanes holding nothing add zeros), so the result is bit-identical to running that kernel on C afterwards.
+  auto ln_piece = [&](int m, const float (&v)[4]) {
+    if constexpr (EPI == EPI_STORE && BN <= 256) {
+      float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+      for (int o = C4 / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mu = s / (float)p.N;
+      const float a = v[0] - mu, b = v[1] - mu, c = v[2] - mu, d = v[3] - mu;
+      float q = (a * a + b * b) + (c * c + d * d);
+#pragma unroll
+      for (int o = C4 / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+      const float rsd = rsqrtf(q / (float)p.N + p.ln_eps);
+      const float4 g = *reinterpret_cast<const float4*>(p.ln_g + n), be = *reinterpret_cast<const float4*>(p.ln_b + n);
+      *reinterpret_cast<float4*>(p.ln_y + (long long)m * p.ln_ld + n) =
+          make_float4((v[0] - mu) * rsd * g.x + be.x, (v[1] - mu) * rsd * g.y + be.y, (v[2] - mu) * rsd * g.z + be.z, (v[3] - mu) * rsd * g.w + be.w);
+      if (cc == 0) {
+        p.ln_mean[m] = mu;
+        p.ln_rstd[m] = rsd;
+      }
+    }
+  };
   // one output row piece (row m, columns n .. n+3, v = the k-complete sums): fused epilogue arithmetic and the global stores
   auto finish = [&](int m, float (&v)[4]) {
     float w2[4];
@@ -640,6 +664,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
     if (p.evec) {
       *reinterpret_cast<float4*>(cptr) = make_float4(v[0], v[1], v[2], v[3]);
       if (EPI == EPI_GELU2) *reinterpret_cast<float4*>(p.C2 + (long long)m * p.ldc2 + n) = make_float4(w2[0], w2[1], w2[2], w2[3]);
+      if (EPI == EPI_STORE && p.ln_y) ln_piece(m, v);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -762,6 +787,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
           }
           *reinterpret_cast<float4*>(Cz + crow * p.ldc + ncol) = make_float4(v[0], v[1], v[2], v[3]);   // (non-temporal stores measured the same: +-1 %)
           if (EPI == EPI_GELU2) *reinterpret_cast<float4*>(p.C2 + crow * p.ldc2 + ncol) = make_float4(w2[0], w2[1], w2[2], w2[3]);
+          if (EPI == EPI_STORE && p.ln_y) ln_piece(m, v);
         }
       }
     } else if (n < p.N) {
@@ -1257,6 +1283,8 @@ int launch_persistent(const GemmParams& p, hipStream_t stream, bool* taken) {
   return DGVIT_OK;
 }
 
+inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
 template <class T, int LAYOUT, int VEC, int EPI, bool GATHER = false>
 int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK;
@@ -1273,6 +1301,12 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
     attr_done = true;
   }
   GemmParams p = p0;
+  if (p.ln_y) {   // fused LayerNorm: the whole output row must sit in this tile's LDS image, vector path
+    DGVIT_CHECK_ARG(EPI == EPI_STORE && VEC == 4 && !GATHER && LAYOUT != GEMM_TN && p.evec && p.N == BN && p.c_rgrp == 0,
+                    "gemm: fused LayerNorm needs the vector EPI_STORE path and N == %d (the tile width), got N = %d", BN, p.N);
+    DGVIT_CHECK_ARG(p.ln_g && p.ln_b && p.ln_mean && p.ln_rstd && p.ln_ld % 4 == 0 && al16(p.ln_g) && al16(p.ln_b) && al16(p.ln_y),
+                    "gemm: fused LayerNorm operands must be present and 16-byte aligned");
+  }
   p.stamps = g_gemm_stamps;
   p.stamp_capacity = g_gemm_stamp_capacity;
   p.diag = g_gemm_diag;
@@ -1293,7 +1327,7 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
     // whole tiles only, vector epilogue, plain row mapping: the persistent kernel (tile loop in the workgroup, next tile's fetch
     // under the epilogue) when a resident slot gets several tiles
     if (g_gemm_persist && (p.nsplit == 1 || g_gemm_persist == 2) && nsplit == 1 && p.evec && p.c_rgrp == 0 && p.res_mod == 0 &&
-        (EPI != EPI_GELU2 || p.ldc2 == p.ldc) && g_gemm_lds_pad == 0) {
+        (EPI != EPI_GELU2 || p.ldc2 == p.ldc) && g_gemm_lds_pad == 0 && !p.ln_y) {
       bool taken = false;
       const int rc = launch_persistent<T, LAYOUT, EPI>(p0, stream, &taken);
       if (rc != DGVIT_OK || taken) return rc;
@@ -1335,7 +1369,6 @@ int pick_tile(const GemmParams& p, int nsplit, bool vec4, int tile_hint, hipStre
   return dgvit_set_error(DGVIT_ERR_ARG, "gemm: unknown tile %d", choice);
 }
 
-inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 }  // namespace
 

@@ -179,6 +179,9 @@ void dgvit_set_grouped_reduce(int on);
  * nearly empty last round of tiles, are split over K inside the launch (partial tiles + last-arriver epilogue, deterministic).
  * 0 = one workgroup per output tile.  Results agree to fp32 rounding (the order of the k-sum changes). */
 void dgvit_set_gemm_split(int on);
+/* A/B knob: 1 (default) for dim == 64 the encoder forward runs its LayerNorms inside the epilogues of the GEMMs that produce their
+ * inputs (to_out -> LN2, fc2 -> the next block's LN1); 0 = separate LayerNorm launches.  Bit-identical results. */
+void dgvit_set_ln_fusion(int on);
 /* diagnostic: request `bytes` more dynamic LDS per fp32 GEMM workgroup than it uses (caps the workgroups per CU: occupancy probes) */
 void dgvit_set_gemm_lds_pad(int bytes);
 /* Diagnostics of the per-tile fp32 GEMM (tools only; default 0).  Bit 0: A/B knob, raise the wave priority (s_setprio 2) of the main

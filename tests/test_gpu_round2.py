@@ -1060,3 +1060,44 @@ def test_direct_gemm_epilogue_stays_inside_c(layout, epi, M, N, K, ldc):
     if epi == 1:
         torch.testing.assert_close(outs[0][1], torch.nn.functional.gelu(ref).float(), atol=3e-4, rtol=1e-5)
         assert torch.equal(outs[0][1], outs[1][1])
+
+
+# ---------------------------------------------------------------- LayerNorm fused into the producing GEMM's epilogue (dim 64)
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,split", [(1, 1), (7, 1), (32, 1), (700, 1), (32, 0), (700, 0)])
+def test_layernorm_fused_into_gemm_epilogue_is_bit_identical(B, split):
+    """dim == 64: to_out / fc2 compute the following LayerNorm in their epilogue (split-K last arriver for few rows, LDS-image
+    epilogue for many).  Outputs and every gradient equal the separate-launch schedule bit for bit, in eval and in train mode."""
+    import dgvit_amd
+    lib = dgvit_amd.load_library()
+    torch.manual_seed(11)
+    model = dgvit_amd.GoTPolicy(2, 2, 4, 4, 64).cuda()
+    g = torch.Generator().manual_seed(B)
+    img = torch.rand(B, 128, 160, generator=g).cuda()
+    ps = torch.rand(B, 2, generator=g).cuda()
+
+    def run(fused, train):
+        lib.dgvit_set_ln_fusion(fused)
+        lib.dgvit_set_gemm_split(split)
+        try:
+            model.train(train)
+            torch.manual_seed(5)           # same embedding-dropout mask in both schedules
+            for p_ in model.parameters():
+                p_.grad = None
+            mean, log_std = model([img, ps])
+            if train:
+                (mean.square().mean() + log_std.square().mean()).backward()
+            torch.cuda.synchronize()
+            grads = [p_.grad.clone() for p_ in model.parameters() if p_.grad is not None]
+            return mean.detach().clone(), log_std.detach().clone(), grads
+        finally:
+            lib.dgvit_set_ln_fusion(1)
+            lib.dgvit_set_gemm_split(1)
+
+    for train in (False, True):
+        a, b = run(1, train), run(0, train)
+        assert torch.isfinite(a[0]).all()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "outputs differ between fused and separate LayerNorm"
+        assert len(a[2]) == len(b[2])
+        for x, y in zip(a[2], b[2]):
+            assert torch.equal(x, y), "a gradient differs between fused and separate LayerNorm"
