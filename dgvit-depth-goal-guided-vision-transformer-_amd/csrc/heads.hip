@@ -35,7 +35,7 @@ struct HeadArgs {
   float* part;                              // [nwg][towers] partial parameter gradients, layout see part_offsets
   long long part_stride;                    // floats per (workgroup, tower)
   int direct;                               // 1: a single row block -> write parameter gradients straight to dparams
-  int dx_add;                               // 1: add to dx instead of writing it (second tower of a twin head)
+  float* dx1;                               // twin head: tower 1 leaves its input gradient here ([B][K0]); head_dx_add_kernel adds it to dx
   float* dw1[2]; float* db1[2]; float* dw2[2]; float* db2[2]; float* dw3[2][2]; float* db3[2][2];
 };
 
@@ -266,14 +266,26 @@ __global__ void __launch_bounds__(256) mlp_head_bwd_kernel(const HeadArgs a) {
           for (int r = 0; r < 16; ++r) {
             const int row = row0 + arow(r, h);
             if (row < a.B) {
-              float* q = d + (long long)row * a.lddx[sg] + kk;
-              *q = a.dx_add ? *q + acc[r] : acc[r];   // tower 1 runs in a second launch behind tower 0 (see mlp_head_backward)
+              // both towers of a twin head run in this launch: tower 0 writes dx, tower 1 its own buffer, added afterwards in a fixed order
+              if (t == 1 && a.dx1) a.dx1[(long long)row * a.K0 + k] = acc[r];
+              else d[(long long)row * a.lddx[sg] + kk] = acc[r];
             }
           }
         }
       }
     }
   }
+}
+
+// dx += dx1 (tower 1's input gradient of a twin head), scattered into the input pieces
+__global__ void __launch_bounds__(256) head_dx_add_kernel(const HeadArgs a) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)a.B * a.K0) return;
+  const int row = (int)(idx / a.K0);
+  int kk = (int)(idx - (long long)row * a.K0), sg = 0;
+  while (sg + 1 < a.nseg && kk >= a.kx[sg]) { kk -= a.kx[sg]; ++sg; }
+  float* d = a.dx[sg];
+  if (d) d[(long long)row * a.lddx[sg] + kk] += a.dx1[idx];
 }
 
 size_t fwd_lds(int KP, int n1, int n2) { return sizeof(float) * HR * ((size_t)(KP + 4) + (n1 + 4) + (n2 + 4)); }
@@ -350,8 +362,9 @@ long long mlp_head_backward_scratch(const dgvit_mlp_desc* d) {
   int K0 = 0;
   for (int s = 0; s < d->nseg; ++s) K0 += d->kx[s];
   const int nwg = (d->batch + HR - 1) / HR;
-  if (nwg == 1) return 4;
-  return (long long)nwg * d->towers * part_offsets(K0, d->n1, d->n2, d->n3, d->heads3).total;
+  const long long dx1 = d->towers == 2 ? (((long long)d->batch * K0 + 3) & ~3ll) : 0;   // tower 1's input gradient of a twin head
+  if (nwg == 1) return 4 + dx1;
+  return (long long)nwg * d->towers * part_offsets(K0, d->n1, d->n2, d->n3, d->heads3).total + dx1;
 }
 
 int mlp_head_backward(const dgvit_mlp_desc* d, const float* const* in, const float* const* params, const float* h1, const float* h2,
@@ -386,34 +399,18 @@ int mlp_head_backward(const dgvit_mlp_desc* d, const float* const* in, const flo
       return dgvit_set_error(DGVIT_ERR_HIP, "mlp_head_backward: hipFuncSetAttribute failed");
     attr = true;
   }
-  // the two towers of a twin head both add into dx: they run as two launches, one behind the other on the stream (tower 0
-  // writes, tower 1 adds), which keeps the sum's order fixed; heads without an input gradient or with one tower are one launch
+  // a twin head runs both towers in ONE launch (blockIdx.y): tower 0 writes dx, tower 1 writes its input gradient to scratch and a
+  // small kernel adds it (x = t0 + t1: the order is fixed); the two towers used to be two launches one behind the other
   bool any_dx = false;
   for (int s = 0; s < a.nseg; ++s) any_dx = any_dx || a.dx[s];
   const bool vec = w1_vec(a);
   const int slot = profile_begin(PROF_OTHER, 0.0, stream);
-  if (a.towers == 2 && any_dx) {
-    // per-tower launches select their tower through blockIdx.y offset: pass a one-tower view
-    for (int t = 0; t < 2; ++t) {
-      HeadArgs b = a;
-      if (t == 1) {   // shift tower 1 into slot 0, remember that it must ADD to dx
-        b.w1[0] = a.w1[1]; b.b1[0] = a.b1[1]; b.w2[0] = a.w2[1]; b.b2[0] = a.b2[1];
-        b.dw1[0] = a.dw1[1]; b.db1[0] = a.db1[1]; b.dw2[0] = a.dw2[1]; b.db2[0] = a.db2[1];
-        for (int j = 0; j < 2; ++j) { b.w3[0][j] = a.w3[1][j]; b.b3[0][j] = a.b3[1][j]; b.dw3[0][j] = a.dw3[1][j]; b.db3[0][j] = a.db3[1][j]; }
-        b.h1 = a.h1 + (long long)a.B * a.n1; b.h2 = a.h2 + (long long)a.B * a.n2;
-        for (int j = 0; j < 2; ++j) b.dyp[0][j] = a.dyp[1][j];
-        b.part = a.part + po.total;
-      }
-      b.towers = 1;
-      b.part_stride = po.total * 2;   // scratch stays [wg][2 towers]
-      b.dx_add = t;
-      if (vec) hipLaunchKernelGGL(mlp_head_bwd_kernel<true>, dim3(nwg, 1), dim3(256), lds, stream, b);
-      else hipLaunchKernelGGL(mlp_head_bwd_kernel<false>, dim3(nwg, 1), dim3(256), lds, stream, b);
-    }
-  } else {
-    a.dx_add = 0;
-    if (vec) hipLaunchKernelGGL(mlp_head_bwd_kernel<true>, dim3(nwg, a.towers), dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL(mlp_head_bwd_kernel<false>, dim3(nwg, a.towers), dim3(256), lds, stream, a);
+  a.dx1 = (a.towers == 2 && any_dx) ? scratch + (need - (((long long)a.B * a.K0 + 3) & ~3ll)) : nullptr;
+  if (vec) hipLaunchKernelGGL(mlp_head_bwd_kernel<true>, dim3(nwg, a.towers), dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL(mlp_head_bwd_kernel<false>, dim3(nwg, a.towers), dim3(256), lds, stream, a);
+  if (a.dx1) {
+    const long long n = (long long)a.B * a.K0;
+    hipLaunchKernelGGL(head_dx_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
   }
   profile_end(slot, stream);
   DGVIT_CHECK_LAUNCH("mlp_head_backward");
