@@ -46,10 +46,20 @@ __device__ __forceinline__ void stage_x(const HeadArgs& a, float* xs, int row0, 
   for (int sg = 0; sg < a.nseg; ++sg) {
     const int kx = a.kx[sg], ld = a.ldx[sg];
     const float* __restrict__ src = a.x[sg];
-#pragma unroll 4
-    for (int f = tid; f < HR * kx; f += 256) {
-      const int r = f / kx, k = f - r * kx;
-      xs[r * SX + koff + k] = row0 + r < a.B ? src[(long long)(row0 + r) * ld + k] : 0.f;
+    // 16 loads in flight per thread and trip (the whole 32 x 290 input of the CNN heads in three trips): the kernel is one
+    // workgroup walking a chain of dependent global round trips, every trip saved is ~1.5 us
+    for (int f0 = tid; f0 < HR * kx; f0 += 256 * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int f = f0 + u * 256, r = f / kx, k = f - r * kx;
+        v[u] = (f < HR * kx && row0 + r < a.B) ? src[(long long)(row0 + r) * ld + k] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int f = f0 + u * 256, r = f / kx, k = f - r * kx;
+        if (f < HR * kx) xs[r * SX + koff + k] = v[u];
+      }
     }
     koff += kx;
   }

@@ -28,6 +28,11 @@ __device__ __forceinline__ void mm_rows_x_wrows(f32x16& acc, const float* a_img,
       const int k = 8 * (g0 + u) + 4 * h;
       if (VEC) {
         b[u] = (jok && g0 + u < ng && k < kmax) ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (((ldw | kmax) & 1) == 0 && (reinterpret_cast<uintptr_t>(W) & 7) == 0) {
+        // rows 8-byte aligned, even K (the CNN heads' 290 inputs): two 8-byte loads instead of four scalar ones
+        const float2 lo = (jok && g0 + u < ng && k + 0 < kmax) ? *reinterpret_cast<const float2*>(wrow + k) : make_float2(0.f, 0.f);
+        const float2 hi = (jok && g0 + u < ng && k + 2 < kmax) ? *reinterpret_cast<const float2*>(wrow + k + 2) : make_float2(0.f, 0.f);
+        b[u] = make_float4(lo.x, lo.y, hi.x, hi.y);
       } else {
         b[u].x = (jok && g0 + u < ng && k + 0 < kmax) ? wrow[k + 0] : 0.f;
         b[u].y = (jok && g0 + u < ng && k + 1 < kmax) ? wrow[k + 1] : 0.f;
