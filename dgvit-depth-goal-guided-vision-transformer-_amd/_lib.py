@@ -60,6 +60,7 @@ SIGNATURES = {
     "dgvit_set_gemm_split": (None, [_I]),
     "dgvit_set_gemm_lds_pad": (None, [_I]),
     "dgvit_set_ln_fusion": (None, [_I]),
+    "dgvit_set_conv_gather": (None, [_I]),
     "dgvit_set_gemm_diagnostics": (None, [_I]),
     "dgvit_set_gemm_persistent": (None, [_I, _I]),
     "dgvit_gemm_persistent_launches": (ctypes.c_longlong, []),

@@ -50,6 +50,10 @@ struct GemmParams {
   // `A` / `lda` are ignored.  Needs pw % 4 == 0, image width % 4 == 0 and a 16-byte aligned image (float4 loads never cross a patch row).
   const float* g_img; long long g_img_floats;
   int g_wi, g_hw, g_ph, g_pw, g_gw, g_P, g_inv;   // image width, image height * width, patch h / w, patches per row / frame, 65536 / pw + 1
+  // the same loader reads strided, overlapping windows (NHWC convolution, C % 4 == 0: g_pw = KW * C window-row floats, g_wi = W * C,
+  // g_hw = H * W * C): g_kh = window rows (0: g_ph), g_ph = row step, g_xs = window step along a row in floats (0: g_pw),
+  // g_shift = the multiply-shift of k / g_pw (0: 16; g_inv = 2^g_shift / g_pw + 1)
+  int g_kh, g_xs, g_shift;
   float* C; int ldc;
   const float* bias;     // [N] or null
   const float* res; int ldr;  // residual [*][N] or null

@@ -265,6 +265,8 @@ extern "C" void dgvit_set_prune_last_layer(int on) { g_prune_last = on ? 1 : 0; 
 extern "C" void dgvit_set_wgrad_overlap(int on) { g_overlap_wgrad = on ? 1 : 0; }
 extern "C" void dgvit_set_grouped_reduce(int on) { g_group_reduce = on ? 1 : 0; }
 static int g_ln_fusion = 1;
+static int g_conv_gather = 1;
+extern "C" void dgvit_set_conv_gather(int on) { g_conv_gather = on ? 1 : 0; }
 extern "C" void dgvit_set_ln_fusion(int on) { g_ln_fusion = on ? 1 : 0; }
 extern "C" void dgvit_set_gemm_split(int on) { g_gemm_split = on ? 1 : 0; }
 extern "C" void dgvit_set_gemm_stamps(long long* stamps, int workgroups) {
@@ -815,9 +817,22 @@ extern "C" int dgvit_cnn_forward(const float* img, const float* const* params, f
   const float* in = img;
   for (int l = 0; l < 3; ++l) {
     TRY(weight_pack(params[2 * l], wp[l], d.C[l + 1], d.C[l], d.KP[l], 0, st));
-    TRY(im2col(in, cols, B, d.H[l], d.W[l], d.C[l], d.H[l + 1], d.W[l + 1], d.KP[l], st));
+    // conv2 / conv3 (NHWC input with 16 / 64 channels): implicit GEMM - the 5x5xC windows go from the activation straight into
+    // the GEMM's A tiles (the patch-gather loader with a window step of 2 C floats), no column matrix.  conv1 (one channel,
+    // 25 -> 28 padded taps) keeps im2col; the backward builds the columns it needs for the weight gradients itself.
+    const int C = d.C[l], pw = 5 * C;
+    const int shift = 24, inv = (1 << shift) / (pw > 0 ? pw : 1) + 1;
+    bool gather = g_conv_gather && C % 4 == 0 && d.KP[l] == 25 * C && ((uintptr_t)in & 15) == 0 && (long long)d.KP[l] * inv < (1ll << 32) &&
+                  (long long)B * d.H[l] * d.W[l] * C < (1ll << 29);
+    for (int k = 0; gather && k < d.KP[l]; ++k) gather = (int)(((unsigned long long)(unsigned)k * (unsigned)inv) >> shift) == k / pw;   // exact k / pw
+    if (!gather) TRY(im2col(in, cols, B, d.H[l], d.W[l], d.C[l], d.H[l + 1], d.W[l + 1], d.KP[l], st));
     GemmParams p = gp(cols, d.KP[l], wp[l], d.KP[l], act[l + 1], d.C[l + 1], (int)d.M[l + 1], d.C[l + 1], d.KP[l]);
     p.bias = params[2 * l + 1];
+    if (gather) {
+      p.g_img = in; p.g_img_floats = (long long)B * d.H[l] * d.W[l] * C;
+      p.g_wi = d.W[l] * C; p.g_hw = d.H[l] * d.W[l] * C; p.g_ph = 2; p.g_kh = 5; p.g_pw = pw; p.g_xs = 2 * C;
+      p.g_gw = d.W[l + 1]; p.g_P = d.H[l + 1] * d.W[l + 1]; p.g_inv = inv; p.g_shift = shift;
+    }
     TRY(gemm_f32(GEMM_NT, EPI_RELU, p, 1, st));   // relu(conv + bias), rows = next layer's NHWC input
     in = act[l + 1];
   }

@@ -86,25 +86,27 @@ struct Fetch {
     int kc[NV];         // KC: k offset of the slot inside a tile; MC: k row of the slot inside a tile
     unsigned bad[NV];   // MC: all ones when the slot's columns lie outside the matrix (OR-ed into the offset: no branch), else 0
     unsigned kstep;     // bytes to advance per k-tile
-    int g_wi, g_pw, g_inv;   // GATHER: image width, patch width, 65536 / pw + 1
+    int g_wi, g_pw, g_inv, g_shift;   // GATHER: image row pitch, window-row floats, 2^shift / pw + 1, shift
   };
 
-  // GATHER: A is never materialised.  Row m of the patch matrix starts at pixel (b, hy * ph, wx * pw) of the image; element k of
-  // the row is p1 = k / pw image rows further down and p2 = k % pw pixels to the right (k / pw by multiply-shift, exact for the
-  // k < 65536 / pw that dgvit_api checks).  The descriptor covers the whole image buffer.
+  // GATHER: A is never materialised.  Row m of the patch matrix starts at pixel (b, hy * ph, wx * xs) of the image; element k of
+  // the row is p1 = k / pw image rows further down and p2 = k % pw floats to the right (k / pw by multiply-shift; dgvit_api checks
+  // that it is exact for every k < K).  Non-overlapping patches (xs = pw) and the strided 5x5 windows of the NHWC convolutions
+  // (xs = stride * C, pw = KW * C) are the same arithmetic.  The descriptor covers the whole image buffer.
   __device__ static __forceinline__ void plan_gather(Plan& pl, const GemmParams& p, int r0, int tid) {
     long long bytes = p.g_img_floats * 4;
     if (bytes > 0x7FFFFFFFll) bytes = 0x7FFFFFFFll;
     pl.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g_img), 0, (int)bytes, 0x00020000);
     pl.kstep = 0;
-    pl.g_wi = p.g_wi; pl.g_pw = p.g_pw; pl.g_inv = p.g_inv;
+    pl.g_wi = p.g_wi; pl.g_pw = p.g_pw; pl.g_inv = p.g_inv; pl.g_shift = p.g_shift ? p.g_shift : 16;
+    const int xs = p.g_xs ? p.g_xs : p.g_pw;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = tid + i * NT;
       const int a = f / PER_ROW, c = (f % PER_ROW) * 4;
       const int m = r0 + a;
       const int b = m / p.g_P, pi = m - b * p.g_P, hy = pi / p.g_gw, wx = pi - hy * p.g_gw;
-      pl.off[i] = ((unsigned)b * (unsigned)p.g_hw + (unsigned)(hy * p.g_ph) * (unsigned)p.g_wi + (unsigned)(wx * p.g_pw)) * 4u;
+      pl.off[i] = ((unsigned)b * (unsigned)p.g_hw + (unsigned)(hy * p.g_ph) * (unsigned)p.g_wi + (unsigned)(wx * xs)) * 4u;
       pl.kc[i] = c;
       pl.bad[i] = m < p.M ? 0u : 0xFFFFFFFFu;
     }
@@ -148,7 +150,7 @@ struct Fetch {
     for (int i = 0; i < NV; ++i) {
       unsigned at;
       if constexpr (GATHER) {
-        const unsigned k = (unsigned)(t * BK + pl.kc[i]), p1 = (k * (unsigned)pl.g_inv) >> 16, p2 = k - p1 * (unsigned)pl.g_pw;
+        const unsigned k = (unsigned)(t * BK + pl.kc[i]), p1 = (k * (unsigned)pl.g_inv) >> pl.g_shift, p2 = k - p1 * (unsigned)pl.g_pw;
         at = (pl.off[i] + (p1 * (unsigned)pl.g_wi + p2) * 4u) | pl.bad[i];
       } else {
         at = (pl.off[i] + (unsigned)t * pl.kstep) | pl.bad[i];   // num_records <= 0x7FFFFFFF: all ones is out of range
@@ -1354,8 +1356,8 @@ inline int auto_tile(int layout, int M, int N) {
 
 template <int LAYOUT, int EPI>
 int pick_tile(const GemmParams& p, int nsplit, bool vec4, int tile_hint, hipStream_t stream) {
-  if constexpr (LAYOUT == GEMM_NT && EPI == EPI_STORE) {
-    if (p.g_img) return launch<TileCfg<64, 64, 32>, LAYOUT, 4, EPI, true>(p, nsplit, stream);   // patch gather in the A loader
+  if constexpr (LAYOUT == GEMM_NT && (EPI == EPI_STORE || EPI == EPI_RELU)) {
+    if (p.g_img) return launch<TileCfg<64, 64, 32>, LAYOUT, 4, EPI, true>(p, nsplit, stream);   // patch / window gather in the A loader
   }
   if (!vec4) return launch<TileCfg<64, 64, 32>, LAYOUT, 1, EPI>(p, nsplit, stream);
   int choice = tile_hint;
@@ -1395,8 +1397,9 @@ GemmSplitPlan gemm_split_plan(int layout, int M, int N, int K) {
 
 int gemm_f32(int layout, int epi, const GemmParams& p, int nsplit, hipStream_t stream) {
   DGVIT_CHECK_ARG((p.A || p.g_img) && p.B && p.C, "gemm: null operand");
-  DGVIT_CHECK_ARG(!p.g_img || (layout == GEMM_NT && epi == EPI_STORE && p.g_pw % 4 == 0 && p.g_wi % 4 == 0 && al16(p.g_img) && al16(p.B) &&
-                               p.ldb % 4 == 0 && p.K % 4 == 0 && p.K == p.g_ph * p.g_pw && (long long)p.K * p.g_inv < (1ll << 31)),
+  DGVIT_CHECK_ARG(!p.g_img || (layout == GEMM_NT && (epi == EPI_STORE || epi == EPI_RELU) && p.g_pw % 4 == 0 && p.g_wi % 4 == 0 && p.g_xs % 4 == 0 &&
+                               al16(p.g_img) && al16(p.B) && p.ldb % 4 == 0 && p.K % 4 == 0 && p.K == (p.g_kh ? p.g_kh : p.g_ph) * p.g_pw &&
+                               (long long)p.K * p.g_inv < (1ll << 32)),
                   "gemm: patch gather needs the NT / store form, patch and image widths that are multiples of 4 and 16-byte aligned operands");
   DGVIT_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
   DGVIT_CHECK_ARG(nsplit >= 1 && p.kchunk > 0 && p.kchunk % 32 == 0, "gemm: kchunk must be a positive multiple of 32");

@@ -182,6 +182,9 @@ void dgvit_set_gemm_split(int on);
 /* A/B knob: 1 (default) for dim == 64 the encoder forward runs its LayerNorms inside the epilogues of the GEMMs that produce their
  * inputs (to_out -> LN2, fc2 -> the next block's LN1); 0 = separate LayerNorm launches.  Bit-identical results. */
 void dgvit_set_ln_fusion(int on);
+/* A/B knob: 1 (default) dgvit_cnn_forward runs conv2 / conv3 as implicit GEMMs (5x5xC windows gathered by the GEMM's A-tile loader);
+ * 0 = im2col + GEMM.  Bit-identical results. */
+void dgvit_set_conv_gather(int on);
 /* diagnostic: request `bytes` more dynamic LDS per fp32 GEMM workgroup than it uses (caps the workgroups per CU: occupancy probes) */
 void dgvit_set_gemm_lds_pad(int bytes);
 /* Diagnostics of the per-tile fp32 GEMM (tools only; default 0).  Bit 0: A/B knob, raise the wave priority (s_setprio 2) of the main

@@ -1101,3 +1101,37 @@ def test_layernorm_fused_into_gemm_epilogue_is_bit_identical(B, split):
         assert len(a[2]) == len(b[2])
         for x, y in zip(a[2], b[2]):
             assert torch.equal(x, y), "a gradient differs between fused and separate LayerNorm"
+
+
+# ---------------------------------------------------------------- implicit-GEMM convolution (conv2 / conv3 forward)
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(1, 128, 160), (5, 128, 160), (32, 128, 160), (3, 84, 84)])
+def test_conv_forward_gather_equals_im2col(B, H, W):
+    """conv2 / conv3 read their 5x5xC windows through the GEMM's A-tile loader (no column matrix): same k order, so the CNN critic's
+    outputs and gradients equal the im2col schedule bit for bit."""
+    import dgvit_amd
+    lib = dgvit_amd.load_library()
+    torch.manual_seed(4)
+    net = dgvit_amd.QNetwork(2, 2).cuda()
+    g = torch.Generator().manual_seed(B + H)
+    img = torch.rand(B, H, W, generator=g).cuda()
+    ps = torch.rand(B, 2, generator=g).cuda()
+    act = (torch.rand(B, 2, generator=g) * 2 - 1).cuda()
+
+    def run(on):
+        lib.dgvit_set_conv_gather(on)
+        try:
+            for p_ in net.parameters():
+                p_.grad = None
+            q1, q2 = net([img, ps, act])
+            (q1.square().mean() + q2.mean()).backward()
+            torch.cuda.synchronize()
+            return q1.detach().clone(), q2.detach().clone(), [p_.grad.clone() for p_ in net.parameters() if p_.grad is not None]
+        finally:
+            lib.dgvit_set_conv_gather(1)
+
+    a, b = run(1), run(0)
+    assert torch.isfinite(a[0]).all()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for x, y in zip(a[2], b[2]):
+        assert torch.equal(x, y)
