@@ -69,6 +69,27 @@ __global__ void __launch_bounds__(256) probe(long long* out, float* sink, int it
       a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, qc.z, a1, 0, 0, 0);
       a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, qb.w, a2, 0, 0, 0);
       a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, qc.w, a3, 0, 0, 0);
+    } else if (KIND == 9 || KIND == 10) {
+      // as 8, plus what a k-tile of the GEMM adds: one workgroup barrier per 16 MFMAs (9), and the 3 LDS tile writes (10)
+      const float4 qa = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + (i & 7) * 1040) & 4092));
+      const float4 qb = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + 2080 + (i & 7) * 1040) & 4092));
+      const float4 qc = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + 1040 + (i & 7) * 1040) & 4092));
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, qb.x, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, qc.x, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, qb.y, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, qc.y, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, qb.z, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, qc.z, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, qb.w, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, qc.w, a1, 0, 0, 0);
+      if (i & 1) {
+        if (KIND == 10) {
+          *reinterpret_cast<float4*>(lds + 4096 + ((threadIdx.x * 4) & 2044)) = make_float4(qa.x, qb.y, qc.z, qa.w);
+          *reinterpret_cast<float4*>(lds + 4096 + ((threadIdx.x * 4 + 1024) & 2044)) = make_float4(qb.x, qc.y, qa.z, qb.w);
+          if (threadIdx.x < 128) *reinterpret_cast<float4*>(lds + 4096 + ((threadIdx.x * 4 + 512) & 2044)) = make_float4(qc.x, qa.y, qb.z, qc.w);
+        }
+        __syncthreads();
+      }
     } else if (KIND == 8) {
       // as 4 with TWO accumulators (the fp32 GEMM's 32 x 64 wave tile): fits 5 workgroups per CU like the real kernel
       const float4 qa = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + (i & 7) * 1040) & 4092));
@@ -153,11 +174,11 @@ void run(const char* name, int wgs, int iters, double flops_per_mfma, int cycles
     std::vector<double> mhz(waves), use(waves);
     for (int i = 0; i < waves; ++i) {
       mhz[i] = (double)h[2 * i] / (double)h[2 * i + 1] * 100.0;
-      use[i] = (KIND == 8 ? 8.0 : (KIND >= 6 ? 16.0 : (KIND >= 3 ? 8.0 : 4.0))) * iters * cycles_per_mfma / (double)h[2 * i];
+      use[i] = ((KIND >= 8) ? 8.0 : (KIND >= 6 ? 16.0 : (KIND >= 3 ? 8.0 : 4.0))) * iters * cycles_per_mfma / (double)h[2 * i];
     }
     std::sort(mhz.begin(), mhz.end());
     std::sort(use.begin(), use.end());
-    const double per_iter = KIND == 8 ? 8.0 : (KIND >= 6 ? 16.0 : (KIND >= 3 ? 8.0 : 4.0));
+    const double per_iter = (KIND >= 8) ? 8.0 : (KIND >= 6 ? 16.0 : (KIND >= 3 ? 8.0 : 4.0));
     const double tf = KIND == 2 ? 0.0 : per_iter * iters * flops_per_mfma * waves / (ms * 1e-3) / 1e12;
     printf("%-28s wgs %5d iters %6d  %8.3f ms  shader clock MHz min/med/max %6.0f %6.0f %6.0f   pipe use med %.3f   %7.1f TFLOP/s\n", name, wgs, iters,
            ms, mhz.front(), mhz[waves / 2], mhz.back(), use[waves / 2], tf);
@@ -181,6 +202,8 @@ int main(int argc, char** argv) {
   run<4>("f32 MFMA + LDS operand reads", wgs, iters / 2, 2.0 * 32 * 32 * 2, 64);
   run<5>("f32 MFMA + LDS + L2 reads", wgs, iters / 2, 2.0 * 32 * 32 * 2, 64);
   run<8>("32x32x2, 2 accumulators + LDS reads", wgs, iters / 2, 2.0 * 32 * 32 * 2, 64);
+  run<9>("  ... + barrier per 16 MFMAs", wgs, iters / 2, 2.0 * 32 * 32 * 2, 64);
+  run<10>("  ... + barrier + LDS tile writes", wgs, iters / 2, 2.0 * 32 * 32 * 2, 64);
   run<6>("v_mfma_f32_16x16x4_f32, random", wgs, iters / 2, 2.0 * 16 * 16 * 4, 32);
   run<7>("16x16x4 f32 + LDS operand reads", wgs, iters / 2, 2.0 * 16 * 16 * 4, 32);
   run<1>("v_mfma_f32_32x32x16_bf16", wgs, iters * 2, 2.0 * 32 * 32 * 16, 32);
