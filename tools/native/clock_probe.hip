@@ -36,6 +36,8 @@ __global__ void __launch_bounds__(256) probe(long long* out, float* sink, int it
       st = st * 1664525u + 1013904223u; ry[i] = (float)(int)(st >> 8) * (1.0f / 8388608.0f) - 1.0f;
     }
   }
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(gsrc), 0, 0x400000, 0x00020000);
+  float4 pre0 = make_float4(0.f, 0.f, 0.f, 0.f), pre1 = pre0, pre2 = pre0;
   float f = x;
   f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
   const long long tc0 = __builtin_readcyclecounter();      // s_memtime: shader clock
@@ -69,6 +71,39 @@ __global__ void __launch_bounds__(256) probe(long long* out, float* sink, int it
       a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, qc.z, a1, 0, 0, 0);
       a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, qb.w, a2, 0, 0, 0);
       a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, qc.w, a3, 0, 0, 0);
+    } else if (KIND == 11 || KIND == 12) {
+      // as 9, plus the k-tile's operand fetch from an L2-resident buffer: 11 = LDS-DMA (buffer_load ... lds: no VGPRs, no ds_write),
+      // 12 = the GEMM's way (16-byte loads into registers, ds_write_b128 one k-tile later); 3 x 16 bytes per thread per 16 MFMAs
+      const float4 qa = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + (i & 7) * 1040) & 4092));
+      const float4 qb = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + 2080 + (i & 7) * 1040) & 4092));
+      const float4 qc = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + 1040 + (i & 7) * 1040) & 4092));
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, qb.x, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, qc.x, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, qb.y, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, qc.y, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, qb.z, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, qc.z, a1, 0, 0, 0);
+      a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, qb.w, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, qc.w, a1, 0, 0, 0);
+      if (i & 1) {
+        const unsigned go = (unsigned)(((threadIdx.x + (i & 1023) * 256 + blockIdx.x * 64) & 0x3FFFF) * 16);
+        if (KIND == 11) {
+          typedef __attribute__((address_space(3))) void* lds_ptr_t;
+          float* dst = lds + 4096 + (threadIdx.x >> 6) * 256 + ((i >> 1) & 1) * 1024;   // wave-uniform base; lane l lands at +16 l bytes
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_ptr_t)dst, 16, go, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_ptr_t)dst, 16, go ^ 0x100000u, 0, 0, 0);
+          if (threadIdx.x < 128) __builtin_amdgcn_raw_ptr_buffer_load_lds(grs, (lds_ptr_t)dst, 16, go ^ 0x200000u, 0, 0, 0);
+          asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // the previous k-tile's DMA has landed
+        } else {
+          *reinterpret_cast<float4*>(lds + 4096 + ((threadIdx.x * 4) & 2044)) = pre0;               // last k-tile's registers -> LDS
+          *reinterpret_cast<float4*>(lds + 4096 + ((threadIdx.x * 4 + 1024) & 2044)) = pre1;
+          if (threadIdx.x < 128) *reinterpret_cast<float4*>(lds + 4096 + ((threadIdx.x * 4 + 512) & 2044)) = pre2;
+          pre0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(grs, go, 0, 0));
+          pre1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(grs, go ^ 0x100000u, 0, 0));
+          if (threadIdx.x < 128) pre2 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(grs, go ^ 0x200000u, 0, 0));
+        }
+        __syncthreads();
+      }
     } else if (KIND == 9 || KIND == 10) {
       // as 8, plus what a k-tile of the GEMM adds: one workgroup barrier per 16 MFMAs (9), and the 3 LDS tile writes (10)
       const float4 qa = *reinterpret_cast<const float4*>(lds + ((threadIdx.x * 4 + (i & 7) * 1040) & 4092));
@@ -139,7 +174,7 @@ __global__ void __launch_bounds__(256) probe(long long* out, float* sink, int it
   }
   const long long tc1 = __builtin_readcyclecounter();
   const long long w1 = wall_clock64();
-  float s = f;
+  float s = f + pre0.x + pre1.y + pre2.z;
   for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
   for (int r = 0; r < 4; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
   if (s == 12345.678f) sink[0] = s;
@@ -204,6 +239,8 @@ int main(int argc, char** argv) {
   run<8>("32x32x2, 2 accumulators + LDS reads", wgs, iters / 2, 2.0 * 32 * 32 * 2, 64);
   run<9>("  ... + barrier per 16 MFMAs", wgs, iters / 2, 2.0 * 32 * 32 * 2, 64);
   run<10>("  ... + barrier + LDS tile writes", wgs, iters / 2, 2.0 * 32 * 32 * 2, 64);
+  run<12>("  ... + barrier + fetch via registers", wgs, iters / 2, 2.0 * 32 * 32 * 2, 64);
+  run<11>("  ... + barrier + fetch via LDS-DMA", wgs, iters / 2, 2.0 * 32 * 32 * 2, 64);
   run<6>("v_mfma_f32_16x16x4_f32, random", wgs, iters / 2, 2.0 * 16 * 16 * 4, 32);
   run<7>("16x16x4 f32 + LDS operand reads", wgs, iters / 2, 2.0 * 16 * 16 * 4, 32);
   run<1>("v_mfma_f32_32x32x16_bf16", wgs, iters * 2, 2.0 * 32 * 32 * 16, 32);
