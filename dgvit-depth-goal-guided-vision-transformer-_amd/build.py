@@ -1,11 +1,18 @@
 """Build libdgvit_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-    python dgvit-depth-goal-guided-vision-transformer-_amd/build.py [--force]
+    python dgvit-depth-goal-guided-vision-transformer-_amd/build.py [--force] [--report]
 
 Objects are rebuilt only when their source (or a header) is newer; the .so travels to the GPU box with
 the repo snapshot (it is git-ignored, not gpurun-ignored).
+
+Register audit: every translation unit is compiled with -Rpass-analysis=kernel-resource-usage; the per-kernel figures
+(VGPRs, AGPRs, scratch bytes per lane, spills, LDS, occupancy) are kept beside the object as <name>.resources.json, and the
+build FAILS when a kernel uses scratch memory or spills registers unless it is named in SPILL_ALLOW below (with the reason).
+`--report` prints the table.
 """
+import json
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -18,7 +25,15 @@ SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "embed.hip", "conv.hip", "op
            "attention_bf16.hip", "misc_bf16.hip", "heads.hip", "frame.hip", "dgvit_api.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "bf16.h"), os.path.join(CSRC, "small_mma.h"), os.path.join(INCLUDE, "dgvit_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-fvisibility=hidden", "-I", INCLUDE]
+         "-Wno-unused-variable", "-fvisibility=hidden", "-I", INCLUDE, "-Rpass-analysis=kernel-resource-usage"]
+
+# Kernels that may use scratch memory (regular expressions on the demangled-free mangled name), each with its reason.
+# Everything else must have ScratchSize == 0 and no spills, or the build stops.
+SPILL_ALLOW = {
+}
+
+_REMARK = re.compile(r"remark: (?:\s*)(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|"
+                     r"VGPRs Spill|LDS Size \[bytes/block\]): (\S+)")
 
 
 def _stale(target, deps):
@@ -28,24 +43,82 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def parse_resources(stderr_text):
+    """[{name, sgprs, vgprs, agprs, scratch, occupancy, sgpr_spill, vgpr_spill, lds}] from the resource-usage remarks."""
+    keys = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch",
+            "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill",
+            "LDS Size [bytes/block]": "lds"}
+    out, cur = [], None
+    for m in _REMARK.finditer(stderr_text):
+        k, v = m.group(1), m.group(2)
+        if k == "Function Name":
+            cur = {"name": v}
+            out.append(cur)
+        elif cur is not None:
+            cur[keys[k]] = int(v)
+    return out
+
+
 def _compile(src):
     obj = os.path.join(CSRC, src.replace(".hip", ".o"))
     path = os.path.join(CSRC, src)
-    subprocess.run(["hipcc", *FLAGS, "-c", path, "-o", obj], check=True)
+    r = subprocess.run(["hipcc", *FLAGS, "-c", path, "-o", obj], capture_output=True, text=True)
+    other = "\n".join(l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l and not re.match(r"^\s+\d* *\|", l)
+                      and "remarks generated" not in l and "remark generated" not in l)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr)
+        raise RuntimeError(f"hipcc failed on {src}")
+    if other.strip():
+        sys.stderr.write(other + "\n")
+    res = parse_resources(r.stderr)
+    with open(obj.replace(".o", ".resources.json"), "w") as f:
+        json.dump(res, f, indent=0)
     return obj
 
 
-def build(force=False, verbose=True):
+def audit(sources=SOURCES):
+    """(all kernels, offenders): offenders use scratch / spill and are not allow-listed."""
+    kernels, bad = [], []
+    for s in sources:
+        p = os.path.join(CSRC, s.replace(".hip", ".resources.json"))
+        if not os.path.exists(p):
+            continue
+        for k in json.load(open(p)):
+            k["file"] = s
+            kernels.append(k)
+            if k.get("scratch", 0) or k.get("vgpr_spill", 0) or k.get("sgpr_spill", 0):
+                if not any(re.search(pat, k["name"]) for pat in SPILL_ALLOW):
+                    bad.append(k)
+    return kernels, bad
+
+
+def _demangle(names):
+    try:
+        r = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True, check=True)
+        return r.stdout.splitlines()
+    except Exception:
+        return names
+
+
+def build(force=False, verbose=True, check_spills=True):
     hipcc = subprocess.run(["which", "hipcc"], capture_output=True, text=True).stdout.strip()
     if not hipcc:
         raise RuntimeError("hipcc not found on PATH; libdgvit_hip.so cannot be built")
     objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES]
-    todo = [s for s, o in zip(SOURCES, objs) if force or _stale(o, [os.path.join(CSRC, s), *HEADERS, __file__])]
+    todo = [s for s, o in zip(SOURCES, objs) if force or _stale(o, [os.path.join(CSRC, s), *HEADERS, __file__])
+            or not os.path.exists(o.replace(".o", ".resources.json"))]
     if todo:
         if verbose:
             print("hipcc gfx950:", " ".join(todo), flush=True)
         with ThreadPoolExecutor(max_workers=min(4, len(todo))) as ex:
             list(ex.map(_compile, todo))
+    if check_spills:
+        kernels, bad = audit()
+        if bad:
+            names = _demangle([k["name"] for k in bad])
+            msg = "\n".join(f"  {k['file']}: {n}: scratch {k.get('scratch', 0)} B/lane, VGPR spills {k.get('vgpr_spill', 0)}, "
+                            f"SGPR spills {k.get('sgpr_spill', 0)} (VGPRs {k.get('vgprs')}, AGPRs {k.get('agprs')})" for k, n in zip(bad, names))
+            raise RuntimeError("kernels with register spills / scratch memory (fix them or allow-list them in build.py with a reason):\n" + msg)
     if todo or _stale(LIB, objs):
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], check=True)
         if verbose:
@@ -53,5 +126,18 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def report():
+    kernels, bad = audit()
+    names = _demangle([k["name"] for k in kernels])
+    for k, n in sorted(zip(kernels, names), key=lambda kn: (-kn[0].get("scratch", 0), kn[0]["file"], kn[1])):
+        print(f"{k['file']:20s} vgpr {k.get('vgprs', 0):3d} agpr {k.get('agprs', 0):3d} sgpr {k.get('sgprs', 0):3d} scratch {k.get('scratch', 0):4d} "
+              f"spill {k.get('vgpr_spill', 0):3d} lds {k.get('lds', 0):6d} occ {k.get('occupancy', 0)}  {n[:150]}")
+    print(f"{len(kernels)} kernels, {len(bad)} with scratch / spills outside the allow list")
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--report" in sys.argv:
+        build(force="--force" in sys.argv, check_spills=False)
+        report()
+    else:
+        build(force="--force" in sys.argv)

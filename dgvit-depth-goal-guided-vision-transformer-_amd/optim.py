@@ -41,7 +41,7 @@ def _no_home():
 class _Home:
     """Parameters living back to back (4-float aligned slots) in one flat buffer, with room for Adam's moments."""
 
-    def __init__(self, params: List[torch.nn.Parameter], sections: List[int] = None):
+    def __init__(self, params: List[torch.Tensor], sections: List[int] = None):
         # sections[i]: which GoT encoder's table parameter i belongs to (-1: none); Adam runs never straddle two sections, so
         # the encoder run can pick up the fused backward's gradient buffer without a copy
         self.sections = list(sections) if sections is not None else [-1] * len(params)
@@ -56,14 +56,36 @@ class _Home:
             off += _al4(p.numel())
         self.numel = off
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=params[0].device)   # zeros: padding lanes stay finite
+        # Optimiser state follows a parameter into its new home: a parameter that has taken Adam steps in another (still intact)
+        # home -- a loose FlatAdam(net.parameters()) home later adopted by the module's, a child module's home swallowed by its
+        # parent's, a layout that changed -- keeps its moments and its step count (torch keeps them in `state[p]`, wherever p lives).
+        carried, intact_cache = [], {}
+        for i, p in enumerate(params):
+            ent = _HOME_OF.get(p)
+            if ent is None or ent[0] is self:
+                continue
+            old, j = ent
+            if id(old) not in intact_cache:
+                intact_cache[id(old)] = old.intact()
+            if old.exp_avg is not None and old.steps[j] > 0:
+                if not intact_cache[id(old)]:
+                    raise _lib.DgvitError("parameter storage was replaced (e.g. by .to()) after optimiser state was built; rebuild the optimiser")
+                carried.append((i, old, j))
+        self.exp_avg = self.exp_avg_sq = self.gflat = None
+        self.steps = [0] * len(params)          # per-parameter Adam step counts (torch keeps `state[p]["step"]`)
+        if carried:
+            m, v = self.moments()
+            for i, old, j in carried:
+                n, o, oo = params[i].numel(), self.offsets[i], old.offsets[j]
+                m[o:o + n].copy_(old.exp_avg[oo:oo + n])
+                v[o:o + n].copy_(old.exp_avg_sq[oo:oo + n])
+                self.steps[i] = old.steps[j]
         for i, (p, o) in enumerate(zip(params, self.offsets)):
             v = self.flat[o:o + p.numel()].view_as(p)
             v.copy_(p.data)
             p.data = v
             _HOME_OF[p] = (self, i)
-        self.exp_avg = self.exp_avg_sq = self.gflat = None
         self.zero_copy_elems = self.copied_elems = 0   # gradient elements Adam consumed in place / had to gather (tests, tuning)
-        self.steps = [0] * len(params)          # per-parameter Adam step counts (torch keeps `state[p]["step"]`)
         self.signature = tuple((tuple(p.shape), o) for p, o in zip(params, self.offsets))
 
     def __deepcopy__(self, memo):
@@ -106,8 +128,8 @@ def _layout(module: torch.nn.Module):
     order, sections, taken, nsec = [], [], set(), 0
     for sub in module.modules():
         if isinstance(sub, GoT):
-            for p in sub.param_table():
-                if p.requires_grad and id(p) not in taken:
+            for p in sub.param_table():     # frozen parameters keep their slot: a frozen target has its source's layout
+                if id(p) not in taken:
                     order.append(p)
                     sections.append(nsec)
                     taken.add(id(p))
@@ -130,12 +152,10 @@ def flatten_parameters(module: torch.nn.Module) -> torch.Tensor:
 def home_of(module: torch.nn.Module) -> _Home:
     h = getattr(module, "_dgvit_home", None)
     lay, sections = _layout(module)
-    if isinstance(h, _Home) and len(h.params) == len(lay) and all(a is b for a, b in zip(h.params, lay)):
-        if h.intact():
-            return h
-        if h.exp_avg is not None:
-            raise _lib.DgvitError("parameter storage was replaced (e.g. by .to()) after optimiser state was built; rebuild the optimiser")
-    h = _Home(lay, sections)
+    if isinstance(h, _Home) and len(h.params) == len(lay) and all(a is b for a, b in zip(h.params, lay)) and h.intact():
+        return h
+    h = _Home(lay, sections)        # (carries over the Adam state of parameters that lived in another intact home; raises if that
+                                    #  home's storage was replaced, e.g. by .to(), after optimiser state was built)
     module._dgvit_home = h
     return h
 
@@ -168,8 +188,8 @@ class FlatAdam:
         for p in items:
             if isinstance(p, torch.nn.Module):
                 continue
-            if not isinstance(p, torch.nn.Parameter):
-                raise TypeError(f"FlatAdam: expected modules or parameters, got {type(p).__name__}")
+            if not (isinstance(p, torch.Tensor) and p.is_leaf and p.dtype == torch.float32):   # nn.Parameter or a plain leaf such as DRL.py's log_alpha
+                raise TypeError(f"FlatAdam: expected modules, parameters or fp32 leaf tensors, got {type(p).__name__}")
             if p.requires_grad and id(p) not in seen:
                 seen.add(id(p))
                 chosen.append(p)
@@ -180,6 +200,17 @@ class FlatAdam:
             _Home(loose)               # parameters handed over one by one that no module home owns yet
         self.params = chosen
         self.step_count = 0
+        # Like a new torch.optim.Adam, a new FlatAdam starts from empty state: moments and step counts live with the parameters'
+        # home (they follow the parameters when a home is rebuilt), so whatever an EARLIER optimiser over the same parameters left
+        # there is cleared here.  load_state_dict() restores a saved state.
+        for p in chosen:
+            home, i = _HOME_OF[p]
+            if home.steps[i]:
+                home.steps[i] = 0
+                if home.exp_avg is not None:
+                    o, n = home.offsets[i], p.numel()
+                    home.exp_avg[o:o + n].zero_()
+                    home.exp_avg_sq[o:o + n].zero_()
 
     def _all_params(self):
         return self.params
@@ -257,6 +288,14 @@ class FlatAdam:
     def state_dict(self):
         """Per parameter (in the optimiser's parameter order): step count and both moments, like torch.optim.Adam's state."""
         state = []
+        if self.capturable and self._step_dev is not None:
+            # graph replays advance only the device counter: bring the host mirror up to date (one device -> host read)
+            dev_step = int(self._step_dev.item())
+            for p in self.params:
+                home, i = _HOME_OF[p]
+                if home.steps[i] > 0:
+                    home.steps[i] = dev_step
+            self.step_count = max(self.step_count, dev_step)
         for p in self.params:
             home, i = _HOME_OF[p]
             o, n = home.offsets[i], p.numel()
