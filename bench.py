@@ -282,12 +282,11 @@ def main():
     from dgvit_amd import _lib
     import synthetic                         # input generator + FLOP model (oracle/ is only imported by cpu_baseline())
     lib = dgvit_amd.load_library()
-    lib.dgvit_set_wgrad_overlap(1 if args.wgrad_overlap else 0)
-    lib.dgvit_set_prune_last_layer(0 if args.dense_last_block else 1)
 
     B = args.batch
     torch.manual_seed(3407)                      # identical initial weights on every rank (config.yaml:7 SEED)
     model = dgvit_amd.GoTPolicy(2, 2, DEPTH, HEADS, DIM, image_size=IMAGE, patch_size=PATCH).to(dev).train()
+    model.trans.set_schedule(dense_last_block=args.dense_last_block, wgrad_overlap=args.wgrad_overlap)   # per-module options (dgvit_config.flags)
     sync = GradSync([model], force_collective=args.force_collective)
     sync.broadcast_parameters(0)
     from dgvit_amd.optim import FlatAdam
@@ -369,7 +368,7 @@ def main():
     # stream.  Not the headline: concurrent kernels stretch each other's durations, so no per-kernel roofline can be quoted for it.
     overlap_ab = None
     if world == 1 and not args.wgrad_overlap and not args.no_overlap_ab:
-        lib.dgvit_set_wgrad_overlap(1)
+        model.trans.set_schedule(dense_last_block=args.dense_last_block, wgrad_overlap=True)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -378,7 +377,7 @@ def main():
             step()
         torch.cuda.synchronize()
         dto = (time.perf_counter() - t0) / args.steps
-        lib.dgvit_set_wgrad_overlap(0)
+        model.trans.set_schedule(dense_last_block=args.dense_last_block, wgrad_overlap=False)
         overlap_ab = {"frames_per_s": round(B / dto, 1), "ms_per_step": round(dto * 1e3, 3),
                       "note": "same step, weight-gradient GEMMs on a helper stream beside the data-gradient chain (DESIGN 3.3); not the headline"}
 

@@ -9,6 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_longlong, c_u
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdgvit_hip.so")
+DIAG_LIB_PATH = os.path.join(_HERE, "libdgvit_hip_diag.so")   # same sources built with -DDGVIT_DIAG: knobs and experiments (tools/, A/B tests)
 
 
 class DgvitError(RuntimeError):
@@ -17,7 +18,11 @@ class DgvitError(RuntimeError):
 
 class dgvit_config(Structure):
     _fields_ = [("image_h", c_int), ("image_w", c_int), ("patch_h", c_int), ("patch_w", c_int), ("dim", c_int),
-                ("depth", c_int), ("heads", c_int), ("dim_head", c_int), ("mlp_dim", c_int), ("pool_mean", c_int)]
+                ("depth", c_int), ("heads", c_int), ("dim_head", c_int), ("mlp_dim", c_int), ("pool_mean", c_int), ("flags", c_int)]
+
+
+FLAG_DENSE_LAST_BLOCK = 1    # include/dgvit_hip.h: DGVIT_FLAG_*
+FLAG_WGRAD_OVERLAP = 2
 
 
 class dgvit_mlp_desc(Structure):
@@ -27,7 +32,7 @@ class dgvit_mlp_desc(Structure):
 
 NUM_GLOBAL_PARAMS = 4
 PARAMS_PER_LAYER = 11
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _P, _I, _LL, _F, _ULL = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 _CFG = POINTER(dgvit_config)
@@ -53,19 +58,6 @@ SIGNATURES = {
     "dgvit_tanh_gaussian_backward": (_I, [_P, _P, _P, _P, _I, _F, _F, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dgvit_gemm_scratch_floats": (_LL, [_I, _I, _I, _I]),
     "dgvit_gemm": (_I, [_I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P, _LL, _P]),
-    "dgvit_set_gemm_tile": (None, [_I]),
-    "dgvit_set_prune_last_layer": (None, [_I]),
-    "dgvit_set_wgrad_overlap": (None, [_I]),
-    "dgvit_set_grouped_reduce": (None, [_I]),
-    "dgvit_set_gemm_split": (None, [_I]),
-    "dgvit_set_gemm_lds_pad": (None, [_I]),
-    "dgvit_set_ln_fusion": (None, [_I]),
-    "dgvit_set_conv_gather": (None, [_I]),
-    "dgvit_set_gemm_diagnostics": (None, [_I]),
-    "dgvit_set_gemm_persistent": (None, [_I, _I]),
-    "dgvit_gemm_persistent_launches": (ctypes.c_longlong, []),
-    "dgvit_set_gemm_stamps": (None, [_P, _I]),
-    "dgvit_set_small_batch_path": (None, [_I, _I]),
     "dgvit_layernorm_forward": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dgvit_layernorm_backward_scratch_floats": (_LL, [_I, _I]),
     "dgvit_layernorm_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _P]),
@@ -100,11 +92,6 @@ SIGNATURES = {
     "dgvit_wgrad_bf16": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _P]),
     "dgvit_cast_f32_bf16": (_I, [_P, _P, _LL, _P]),
     "dgvit_gemm_bf16": (_I, [_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _P, _I, _P, _I, _P]),
-    "dgvit_set_gemm_bf16_tile": (None, [_I]),
-    "dgvit_set_gemm_bf16_group_m": (None, [_I]),
-    "dgvit_set_attention_bwd_single_pass": (None, [_I]),
-    "dgvit_set_gemm_bf16_mfma16": (None, [_I]),
-    "dgvit_set_gemm_bf16_stamps": (None, [_P]),
     "dgvit_layernorm_forward_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dgvit_attention_forward_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dgvit_attention_backward_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -113,32 +100,80 @@ SIGNATURES = {
     "dgvit_profile_sampling": (_I, [_I]),
     "dgvit_profile_totals": (_I, [POINTER(ctypes.c_double), POINTER(c_longlong)]),
 }
+# the additional entry points of libdgvit_hip_diag.so (include/dgvit_hip_diag.h)
+DIAG_SIGNATURES = {
+    "dgvit_set_gemm_tile": (None, [_I]),
+    "dgvit_set_grouped_reduce": (None, [_I]),
+    "dgvit_set_gemm_split": (None, [_I]),
+    "dgvit_set_gemm_lds_pad": (None, [_I]),
+    "dgvit_set_ln_fusion": (None, [_I]),
+    "dgvit_set_conv_gather": (None, [_I]),
+    "dgvit_set_gemm_diagnostics": (None, [_I]),
+    "dgvit_set_gemm_persistent": (None, [_I, _I]),
+    "dgvit_gemm_persistent_launches": (ctypes.c_longlong, []),
+    "dgvit_set_gemm_stamps": (None, [_P, _I]),
+    "dgvit_set_small_batch_path": (None, [_I, _I]),
+    "dgvit_set_gemm_bf16_tile": (None, [_I]),
+    "dgvit_set_gemm_bf16_group_m": (None, [_I]),
+    "dgvit_set_attention_bwd_single_pass": (None, [_I]),
+    "dgvit_set_gemm_bf16_mfma16": (None, [_I]),
+    "dgvit_set_gemm_bf16_stamps": (None, [_P]),
+}
 PROFILE_KINDS = 4
 
-_lib = None
+_lib = None        # the library the package's calls go through (the product library unless diagnostic() is active)
+_product = None
+_diag = None
 
 
-def load():
-    """Load (once) and type the shared library; raise DgvitError if it is missing or stale."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise DgvitError(f"{LIB_PATH} not found: build it with `python {os.path.join(_HERE, 'build.py')}` "
+def _open(path, signatures):
+    if not os.path.exists(path):
+        raise DgvitError(f"{path} not found: build it with `python {os.path.join(_HERE, 'build.py')}` "
                          "(hipcc --offload-arch=gfx950). There is no fallback path.")
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in signatures.items():
         try:
             fn = getattr(lib, name)
         except AttributeError as e:
-            raise DgvitError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            raise DgvitError(f"{path} does not export {name}; rebuild it") from e
         fn.restype, fn.argtypes = res, args
     if lib.dgvit_abi_version() != ABI_VERSION:
         raise DgvitError(f"ABI mismatch: library {lib.dgvit_abi_version()} != binding {ABI_VERSION}")
     if lib.dgvit_config_size() != ctypes.sizeof(dgvit_config):
         raise DgvitError(f"dgvit_config is {ctypes.sizeof(dgvit_config)} bytes in the binding, {lib.dgvit_config_size()} in the library")
-    _lib = lib
     return lib
+
+
+def load():
+    """The library every call of the package goes through: libdgvit_hip.so (loaded and typed once; DgvitError if it is missing or
+    stale), or the diagnostic build while a ``diagnostic()`` block is active."""
+    global _lib, _product
+    if _lib is not None:
+        return _lib
+    if _product is None:
+        _product = _open(LIB_PATH, SIGNATURES)
+    _lib = _product
+    return _lib
+
+
+class diagnostic:
+    """``with diagnostic() as lib:`` routes the package through libdgvit_hip_diag.so (the -DDGVIT_DIAG build with the A/B knobs
+    and experiments of include/dgvit_hip_diag.h) and yields it; the product library is back on exit.  Not thread-safe; for
+    tools/ and the A/B equality tests, never for the product path."""
+
+    def __enter__(self):
+        global _lib, _diag
+        load()
+        if _diag is None:
+            _diag = _open(DIAG_LIB_PATH, {**SIGNATURES, **DIAG_SIGNATURES})
+        self._prev = _lib
+        _lib = _diag
+        return _diag
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._prev
+        return False
 
 
 def check(rc, what):

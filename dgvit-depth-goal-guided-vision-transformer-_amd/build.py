@@ -21,9 +21,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libdgvit_hip.so")
+LIB_DIAG = os.path.join(HERE, "libdgvit_hip_diag.so")   # the same sources with -DDGVIT_DIAG: knobs, stamps, experiments (tools/, A/B tests)
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "embed.hip", "conv.hip", "optim.hip", "profile.hip", "preprocess.hip", "gemm_bf16.hip",
-           "attention_bf16.hip", "misc_bf16.hip", "heads.hip", "frame.hip", "dgvit_api.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "bf16.h"), os.path.join(CSRC, "small_mma.h"), os.path.join(INCLUDE, "dgvit_hip.h")]
+           "attention_bf16.hip", "misc_bf16.hip", "heads.hip", "dgvit_api.hip"]
+DIAG_ONLY_SOURCES = ["frame.hip"]    # experiments that are not part of the product library
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "bf16.h"), os.path.join(CSRC, "small_mma.h"),
+           os.path.join(CSRC, "knobs.h"), os.path.join(INCLUDE, "dgvit_hip.h"), os.path.join(INCLUDE, "dgvit_hip_diag.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-fvisibility=hidden", "-I", INCLUDE, "-Rpass-analysis=kernel-resource-usage"]
 
@@ -59,10 +62,16 @@ def parse_resources(stderr_text):
     return out
 
 
-def _compile(src):
-    obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+def _obj(src, diag):
+    return os.path.join(CSRC, "diag" if diag else "", src.replace(".hip", ".o"))
+
+
+def _compile(job):
+    src, diag = job
+    obj = _obj(src, diag)
+    os.makedirs(os.path.dirname(obj), exist_ok=True)
     path = os.path.join(CSRC, src)
-    r = subprocess.run(["hipcc", *FLAGS, "-c", path, "-o", obj], capture_output=True, text=True)
+    r = subprocess.run(["hipcc", *FLAGS, *(["-DDGVIT_DIAG"] if diag else []), "-c", path, "-o", obj], capture_output=True, text=True)
     other = "\n".join(l for l in r.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l and not re.match(r"^\s+\d* *\|", l)
                       and "remarks generated" not in l and "remark generated" not in l)
     if r.returncode != 0:
@@ -76,17 +85,17 @@ def _compile(src):
     return obj
 
 
-def audit(sources=SOURCES):
+def audit(sources=SOURCES, diag=False):
     """(all kernels, offenders): offenders use scratch / spill and are not allow-listed."""
     kernels, bad = [], []
     for s in sources:
-        p = os.path.join(CSRC, s.replace(".hip", ".resources.json"))
+        p = _obj(s, diag).replace(".o", ".resources.json")
         if not os.path.exists(p):
             continue
         for k in json.load(open(p)):
             k["file"] = s
             kernels.append(k)
-            if k.get("scratch", 0) or k.get("vgpr_spill", 0) or k.get("sgpr_spill", 0):
+            if k.get("scratch", 0) or k.get("vgpr_spill", 0):     # (SGPR "spills" go to VGPR lanes: no memory traffic, reported only)
                 if not any(re.search(pat, k["name"]) for pat in SPILL_ALLOW):
                     bad.append(k)
     return kernels, bad
@@ -100,17 +109,20 @@ def _demangle(names):
         return names
 
 
-def build(force=False, verbose=True, check_spills=True):
+def build(force=False, verbose=True, check_spills=True, diag=True):
+    """Compile and link libdgvit_hip.so (the product) and, with diag=True, libdgvit_hip_diag.so (same sources, -DDGVIT_DIAG).
+    The register audit gates the PRODUCT library; the diagnostic library's experiments may spill (they are reported, not fatal)."""
     hipcc = subprocess.run(["which", "hipcc"], capture_output=True, text=True).stdout.strip()
     if not hipcc:
         raise RuntimeError("hipcc not found on PATH; libdgvit_hip.so cannot be built")
-    objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES]
-    todo = [s for s, o in zip(SOURCES, objs) if force or _stale(o, [os.path.join(CSRC, s), *HEADERS, __file__])
-            or not os.path.exists(o.replace(".o", ".resources.json"))]
+    jobs = [(s, False) for s in SOURCES] + ([(s, True) for s in SOURCES + DIAG_ONLY_SOURCES] if diag else [])
+    todo = [(s, d) for s, d in jobs if force or _stale(_obj(s, d), [os.path.join(CSRC, s), *HEADERS, __file__])
+            or not os.path.exists(_obj(s, d).replace(".o", ".resources.json"))]
     if todo:
         if verbose:
-            print("hipcc gfx950:", " ".join(todo), flush=True)
-        with ThreadPoolExecutor(max_workers=min(4, len(todo))) as ex:
+            print("hipcc gfx950:", " ".join(s + ("[diag]" if d else "") for s, d in todo), flush=True)
+        todo.sort(key=lambda j: -os.path.getsize(os.path.join(CSRC, j[0])))     # longest compiles first
+        with ThreadPoolExecutor(max_workers=min(7, len(todo))) as ex:
             list(ex.map(_compile, todo))
     if check_spills:
         kernels, bad = audit()
@@ -119,15 +131,19 @@ def build(force=False, verbose=True, check_spills=True):
             msg = "\n".join(f"  {k['file']}: {n}: scratch {k.get('scratch', 0)} B/lane, VGPR spills {k.get('vgpr_spill', 0)}, "
                             f"SGPR spills {k.get('sgpr_spill', 0)} (VGPRs {k.get('vgprs')}, AGPRs {k.get('agprs')})" for k, n in zip(bad, names))
             raise RuntimeError("kernels with register spills / scratch memory (fix them or allow-list them in build.py with a reason):\n" + msg)
-    if todo or _stale(LIB, objs):
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], check=True)
-        if verbose:
-            print("linked", LIB, flush=True)
+    for lib, d, srcs in ((LIB, False, SOURCES), (LIB_DIAG, True, SOURCES + DIAG_ONLY_SOURCES)):
+        if d and not diag:
+            continue
+        objs = [_obj(s, d) for s in srcs]
+        if _stale(lib, objs):
+            subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], check=True)
+            if verbose:
+                print("linked", lib, flush=True)
     return LIB
 
 
-def report():
-    kernels, bad = audit()
+def report(diag=False):
+    kernels, bad = audit(SOURCES + (DIAG_ONLY_SOURCES if diag else []), diag)
     names = _demangle([k["name"] for k in kernels])
     for k, n in sorted(zip(kernels, names), key=lambda kn: (-kn[0].get("scratch", 0), kn[0]["file"], kn[1])):
         print(f"{k['file']:20s} vgpr {k.get('vgprs', 0):3d} agpr {k.get('agprs', 0):3d} sgpr {k.get('sgprs', 0):3d} scratch {k.get('scratch', 0):4d} "
@@ -138,6 +154,6 @@ def report():
 if __name__ == "__main__":
     if "--report" in sys.argv:
         build(force="--force" in sys.argv, check_spills=False)
-        report()
+        report(diag="--diag" in sys.argv)
     else:
         build(force="--force" in sys.argv)

@@ -517,18 +517,17 @@ __global__ void __launch_bounds__(256, 2) attn_bwd64_kernel(const float* __restr
   }
 }
 
-int g_attn_bwd64 = 1;   // A/B knob: 0 = the two-phase kernel for every shape
 
 template <int DH>
 int launch_bwd64(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, int B, int N, int H, float scale,
                  hipStream_t stream) {
   constexpr size_t lds = (size_t)(2 * 64 * (DH + 4) + 2 * 64 * 68) * sizeof(float);
   auto kern = attn_bwd64_kernel<DH>;
-  static bool done = false;
-  if (!done) {
+  static DeviceOnce once;
+  if (const unsigned long long bit = once.pending()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return dgvit_set_error(DGVIT_ERR_HIP, "attention_bwd: %s", hipGetErrorString(e));
-    done = true;
+    once.mark(bit);
   }
   const int slot = profile_begin(PROF_ATTN_BWD, 8.0 * B * H * (double)N * N * DH, stream);
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(256), lds, stream, qkv, o, dout, lse, dqkv, N, H, scale);
@@ -544,12 +543,12 @@ int launch_fwd(const float* qkv, float* out, float* lse, int B, int N, int H, fl
   const int NP = (N + 31) / 32 * 32;
   const size_t lds = (size_t)2 * NP * (DH + 4) * sizeof(float);
   auto kern = attn_fwd_kernel<DH, NW, NKT_CT>;
-  static bool done = false;
-  if (!done) {
+  static DeviceOnce once;
+  if (const unsigned long long bit = once.pending()) {
     const int maxlds = 2 * MAX_TOKENS * (DH + 4) * (int)sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
     if (e != hipSuccess) return dgvit_set_error(DGVIT_ERR_HIP, "attention_fwd: %s", hipGetErrorString(e));
-    done = true;
+    once.mark(bit);
   }
   const int slot = profile_begin(PROF_ATTN_FWD, 4.0 * B * H * (double)nq * N * DH, stream);
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(64 * NW), lds, stream, qkv, out, lse, N, H, scale, nq);
@@ -564,12 +563,12 @@ int launch_bwd(const float* qkv, const float* o, const float* dout, const float*
   const int NP = (N + 31) / 32 * 32;
   const size_t lds = ((size_t)2 * NP * (DH + 4) + 2 * NP) * sizeof(float);
   auto kern = attn_bwd_kernel<DH, NW, NKT_CT>;
-  static bool done = false;
-  if (!done) {
+  static DeviceOnce once;
+  if (const unsigned long long bit = once.pending()) {
     const int maxlds = (2 * MAX_TOKENS * (DH + 4) + 2 * MAX_TOKENS) * (int)sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds);
     if (e != hipSuccess) return dgvit_set_error(DGVIT_ERR_HIP, "attention_bwd: %s", hipGetErrorString(e));
-    done = true;
+    once.mark(bit);
   }
   const int slot = profile_begin(PROF_ATTN_BWD, 8.0 * B * H * (double)nq * N * DH, stream);
   hipLaunchKernelGGL(kern, dim3(B * H), dim3(64 * NW), lds, stream, qkv, o, dout, lse, dqkv, N, H, scale, nq);
@@ -606,7 +605,6 @@ int attention_fwd(const float* qkv, float* out, float* lse, int B, int N, int H,
 
 // dqkv (B, N, 3*H*dh); with nq < N only rows < nq of `o`/`dout`/`lse` are read and only rows < nq of dq are written
 // (dk, dv: all rows)
-void attention_bwd_single_pass(int on) { g_attn_bwd64 = on ? 1 : 0; }
 
 int attention_bwd(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, int B, int N, int H,
                   int dh, int nq, hipStream_t stream) {

@@ -449,14 +449,14 @@ int attention_bwd_bf16(const bf16_t* qkv, const bf16_t* out, const bf16_t* dout,
   const int NP = (N + 31) / 32 * 32;
   const size_t lds_q = (size_t)2 * NP * 128 + (size_t)64 * (NP + 8) * 2;
   const size_t lds_kv = (size_t)2 * NP * 128 + (size_t)2 * 64 * (NP + 8) * 2 + (size_t)2 * NP * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static DeviceOnce once;
+  if (const unsigned long long bit = once.pending()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) !=
             hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return dgvit_set_error(DGVIT_ERR_HIP, "attention_bwd_bf16: cannot raise the dynamic LDS limit");
-    attr_done = true;
+    once.mark(bit);
   }
   const float scale = 1.0f / sqrtf((float)dh);
   const double flops = 10.0 * (double)N * N * dh * H * B;   // 2.5 x forward

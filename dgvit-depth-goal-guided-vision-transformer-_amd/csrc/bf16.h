@@ -37,10 +37,6 @@ struct GemmBf16Params {
 };
 
 int gemm_bf16(int epi, const GemmBf16Params& p, hipStream_t st);
-extern int g_gemm_bf16_tile_hint;
-extern int g_gemm_bf16_m16;
-extern int g_gemm_bf16_group_m;
-extern long long* g_gemm_bf16_stamps;
 
 int cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t st);
 int patchify_bf16(const float* img, bf16_t* patches, int B, int ih, int iw, int ph, int pw, hipStream_t st);

@@ -3,7 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/dgvit_hip.h"
+#include "knobs.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -21,6 +24,20 @@ int dgvit_set_error(int code, const char* fmt, ...);
     hipError_t e_ = hipGetLastError();                                                           \
     if (e_ != hipSuccess) return dgvit_set_error(DGVIT_ERR_HIP, "%s: %s", name, hipGetErrorString(e_)); \
   } while (0)
+
+// Kernel attributes (the dynamic-LDS limit above 64 KB) are per DEVICE: a flag per device ordinal, set on the first launch on
+// that device (a process-wide `static bool` would leave a second GPU of a single-process host without the attribute).
+// Racing threads may both set the attribute: harmless, it is idempotent.
+struct DeviceOnce {
+  std::atomic<unsigned long long> done{0};
+  unsigned long long pending() const {    // 0: already done on the current device, else the device's bit for mark()
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    return (done.load(std::memory_order_relaxed) & bit) ? 0ull : bit;
+  }
+  void mark(unsigned long long bit) { done.fetch_or(bit, std::memory_order_relaxed); }
+};
 
 // ---- GEMM -----------------------------------------------------------------------------------
 // C[m][n] = sum_k Aop[m][k] * Bop[k][n]   (fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32)

@@ -9,12 +9,20 @@
 #include "common.h"
 #include "kernels.h"
 
-static int g_prune_last = 1;  // last block: only token 0 feeds the output (GoalFormer.py:167)
-static int g_overlap_wgrad = 0;  // opt-in: run weight-gradient GEMMs on a helper stream beside the data-gradient chain
-static int g_small_path = 0;     // opt-in: inference as two launches per block (frame.hip).  Measured on MI355X: slower than
-                                 // the split-K GEMM schedule at B = 1 (0.34 vs 0.20 ms per sample()) and at B = 32 (0.41 vs 0.33), so it is OFF
-static int g_small_path_max_rows = 4160;   // token rows (B * N) up to which the per-frame kernels are used
-static int g_group_reduce = 1;   // one grouped slab / partial reduction per layer (0: one launch per weight gradient, A/B knob)
+// Schedule options travel with every call in dgvit_config.flags (the forward and its backward see the same value, whatever thread
+// runs them); A/B and diagnostic knobs are compile-time constants in this build unless DGVIT_DIAG is defined (knobs.h).
+#ifdef DGVIT_DIAG
+#include "../../include/dgvit_hip_diag.h"
+int g_gemm_tile_hint = 0, g_gemm_split = 1, g_gemm_lds_pad = 0, g_gemm_persist = 0, g_gemm_persist_grid = 0, g_gemm_diag = 0;
+long long* g_gemm_stamps = nullptr;
+int g_gemm_stamp_capacity = 0;
+long long g_gemm_persist_launches = 0;
+int g_group_reduce = 1, g_ln_fusion = 1, g_conv_gather = 1, g_small_path = 0, g_small_path_max_rows = 4160;
+int g_gemm_bf16_tile_hint = 0, g_gemm_bf16_m16 = 1, g_gemm_bf16_group_m = 8, g_attn_bwd64 = 1;
+long long* g_gemm_bf16_stamps = nullptr;
+#endif
+static inline bool dense_last_block(const dgvit_config* c) { return (c->flags & DGVIT_FLAG_DENSE_LAST_BLOCK) != 0; }
+static inline bool wgrad_overlap(const dgvit_config* c) { return (c->flags & DGVIT_FLAG_WGRAD_OVERLAP) != 0; }
 
 // ---------------------------------------------------------------------------------------------- helper stream
 // dgvit_got_backward forks every weight-gradient GEMM (+ its slab reduction) onto one internal non-blocking
@@ -242,7 +250,9 @@ Ws make_ws(const Dims& d, int save) {
     // residual-stream buffer placed right behind it, even layers into the shared `xout`
     w.layer_stride = 0;
     long long region = l + al4(d.T * d.D);
+#ifdef DGVIT_DIAG
     if (frame_path_supports(d.B, d.N, d.D, d.H, d.dh, d.M)) region = std::max(region, al4(frame_path_scratch_floats(d.B, d.N, d.D, d.H, d.M)));
+#endif
     o += region;
   }
   w.total = o;
@@ -260,12 +270,9 @@ extern "C" int dgvit_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return -1;
   return n;
 }
+#ifdef DGVIT_DIAG   // include/dgvit_hip_diag.h: libdgvit_hip_diag.so only
 extern "C" void dgvit_set_gemm_tile(int tile) { g_gemm_tile_hint = tile; }
-extern "C" void dgvit_set_prune_last_layer(int on) { g_prune_last = on ? 1 : 0; }
-extern "C" void dgvit_set_wgrad_overlap(int on) { g_overlap_wgrad = on ? 1 : 0; }
 extern "C" void dgvit_set_grouped_reduce(int on) { g_group_reduce = on ? 1 : 0; }
-static int g_ln_fusion = 1;
-static int g_conv_gather = 1;
 extern "C" void dgvit_set_conv_gather(int on) { g_conv_gather = on ? 1 : 0; }
 extern "C" void dgvit_set_ln_fusion(int on) { g_ln_fusion = on ? 1 : 0; }
 extern "C" void dgvit_set_gemm_split(int on) { g_gemm_split = on ? 1 : 0; }
@@ -284,6 +291,12 @@ extern "C" void dgvit_set_small_batch_path(int on, int max_rows) {
   g_small_path = on ? 1 : 0;
   if (max_rows > 0) g_small_path_max_rows = max_rows;
 }
+extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = tile; }
+extern "C" void dgvit_set_gemm_bf16_mfma16(int on) { g_gemm_bf16_m16 = on ? 1 : 0; }
+extern "C" void dgvit_set_attention_bwd_single_pass(int on) { g_attn_bwd64 = on ? 1 : 0; }
+extern "C" void dgvit_set_gemm_bf16_group_m(int rows) { g_gemm_bf16_group_m = rows > 0 ? rows : 8; }
+extern "C" void dgvit_set_gemm_bf16_stamps(long long* stamps) { g_gemm_bf16_stamps = stamps; }
+#endif   // DGVIT_DIAG
 
 // ---------------------------------------------------------------------------------------------- encoder
 extern "C" long long dgvit_got_workspace_floats(const dgvit_config* cfg, int batch, int save) {
@@ -394,8 +407,10 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
   if (keep < 1.f) TRY(dropout_inplace(x, d.T * d.D, seed, seed_dev, keep, st));
 
   // inference on a handful of frames (SAC.choose_action, the no-grad passes of learn() at batch 32): two launches per block
+#ifdef DGVIT_DIAG   // (measured slower than the schedule below, DESIGN 3.7: not in the product library)
   if (!save && g_small_path && !d.pool_mean && d.T <= g_small_path_max_rows && frame_path_supports(d.B, d.N, d.D, d.H, d.dh, d.M))
     return frame_path_forward(x, params, d.L, ws + w.layer0, feat, d.B, d.N, d.D, d.H, d.dh, d.M, st);
+#endif
 
   const bool ln_fused = g_ln_fusion && d.D == 64 && g_gemm_tile_hint == 0;   // (the automatic tile for N = 64 is 64 wide)
   for (int i = 0; i < d.L; ++i) {
@@ -405,7 +420,7 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     // The output only reads token 0 of the last block (GoalFormer.py:167): there, K and V are needed for every
     // token but Q, the attention output, to_out and the whole feed-forward only for row b*N of each frame.
     // `tok` = rows processed, `rs` = row step (in token rows) of those rows inside the (T, .) buffers.
-    const bool last = g_prune_last && !d.pool_mean && i == d.L - 1;
+    const bool last = !dense_last_block(cfg) && !d.pool_mean && i == d.L - 1;
     const int tok = last ? d.B : T, rs = last ? d.N : 1;
     // x = attn(LN(x)) + x   (GoalFormer.py:103, 36-37, 71-82)
     // D <= 64 (the shipped model): a 64-wide GEMM tile holds whole rows of the residual stream, so each LayerNorm runs inside the
@@ -500,7 +515,7 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
   // weight gradients run on the helper stream `sw`; `done[j]` = main must wait for the previous layer's j-th
   // wgrad before overwriting the buffer it reads (dx, dh1, dx2, dqkv)
   hipStream_t sw = st;
-  if (g_overlap_wgrad) {
+  if (wgrad_overlap(cfg)) {
     TRY(side_init());
     sw = g_side.stream;
     TRY(chain(st, sw));   // helper starts after everything already queued by the caller
@@ -524,7 +539,7 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
     float* const* lg = grads + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
     const float* lb = ws + w.layer0 + w.layer_stride * i;
     const float* xin = i == 0 ? ws + w.x0 : ws + w.layer0 + w.layer_stride * (i - 1) + w.xout;
-    const bool last = g_prune_last && !d.pool_mean && i == d.L - 1;   // see dgvit_got_forward: only rows b*N carry gradient here
+    const bool last = !dense_last_block(cfg) && !d.pool_mean && i == d.L - 1;   // see dgvit_got_forward: only rows b*N carry gradient here
     const int tok = last ? d.B : T, rs = last ? d.N : 1;
     // ---- feed-forward branch: xout = fc2(gelu(fc1(ln2))) + xmid
     // (helper-stream kernels are ordered among themselves, so the slab scratch is reused safely; a `join` before
@@ -1083,12 +1098,6 @@ Bsb make_bsb(const Dims& d) {
 
 }  // namespace
 
-extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = tile; }
-extern "C" void dgvit_set_gemm_bf16_mfma16(int on) { g_gemm_bf16_m16 = on ? 1 : 0; }
-extern "C" void dgvit_set_attention_bwd_single_pass(int on) { attention_bwd_single_pass(on); }
-extern "C" void dgvit_set_gemm_bf16_group_m(int rows) { g_gemm_bf16_group_m = rows > 0 ? rows : 8; }
-extern "C" void dgvit_set_gemm_bf16_stamps(long long* stamps) { g_gemm_bf16_stamps = stamps; }
-
 extern "C" long long dgvit_got_bf16_weight_elems(const dgvit_config* cfg) {
   Dims d;
   if (make_dims(cfg, 1, d) || check_bf16_dims(d)) return -1;
@@ -1185,7 +1194,7 @@ extern "C" int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* cons
     float* xmid = (float*)(lb + w.xmid);
     bf16_t* a1 = (bf16_t*)(lb + w.a1);
     // inference: the last block only needs token 0 downstream of K/V (see dgvit_got_forward); training keeps it dense
-    const bool last = g_prune_last && !save && !d.pool_mean && i == d.L - 1;
+    const bool last = !dense_last_block(cfg) && !save && !d.pool_mean && i == d.L - 1;
     const int tok = last ? d.B : T, rs = last ? d.N : 1;
     float* xo = save ? (float*)(lb + w.xout) : (x == (float*)(ws + w.xa) ? (float*)(ws + w.xb) : (float*)(ws + w.xa));
     if (!last) {

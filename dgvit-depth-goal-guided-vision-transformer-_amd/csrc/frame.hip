@@ -276,12 +276,12 @@ size_t mlp_lds(int NP, int D) { return sizeof(float) * ((size_t)NP * (D + 4) + (
 template <int NKT>
 int launch_pair(const FrameArgs& aa, const FrameArgs& ab, hipStream_t st) {
   const size_t la = attn_lds(aa.NP, aa.D, aa.dh), lb = mlp_lds(ab.NP, ab.D);
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce once;
+  if (const unsigned long long bit = once.pending()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(frame_attn_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(frame_mlp_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return dgvit_set_error(DGVIT_ERR_HIP, "frame kernels: hipFuncSetAttribute failed");
-    attr = true;
+    once.mark(bit);
   }
   const int slot = profile_begin(PROF_OTHER, 0.0, st);
   hipLaunchKernelGGL(frame_attn_kernel<NKT>, dim3(aa.B * aa.H), dim3(256), la, st, aa);

@@ -32,14 +32,6 @@
     if (rc_) return rc_;  \
   } while (0)
 
-extern int g_gemm_split;
-extern int g_gemm_lds_pad;
-extern int g_gemm_persist;
-extern int g_gemm_persist_grid;
-extern long long g_gemm_persist_launches;
-extern int g_gemm_diag;
-extern long long* g_gemm_stamps;
-extern int g_gemm_stamp_capacity;
 
 namespace {
 
@@ -273,6 +265,7 @@ __device__ __forceinline__ void sched_pattern() {
 
 // diagnostic stamps (dgvit_set_gemm_stamps): wave 0 of every workgroup records the shader clock at four points and where it ran
 __device__ __forceinline__ void stamp(const GemmParams& p, int slot, int tid) {
+#ifdef DGVIT_DIAG
   if (p.stamps && tid == 0 && (int)blockIdx.x < p.stamp_capacity) {
     long long* s = p.stamps + (long long)blockIdx.x * 16;
     s[slot] = __builtin_readcyclecounter();
@@ -282,7 +275,16 @@ __device__ __forceinline__ void stamp(const GemmParams& p, int slot, int tid) {
     }
     if (slot == 3) s[6] = wall_clock64();
   }
+#endif
 }
+// timing / A-B diagnostics of the per-tile kernel exist in the diagnostic build only (knobs.h)
+#ifdef DGVIT_DIAG
+#define DIAG_BIT(p, b) ((p).diag & (b))
+#define DIAG_STAMPS(p) ((p).stamps != nullptr)
+#else
+#define DIAG_BIT(p, b) 0
+#define DIAG_STAMPS(p) false
+#endif
 
 template <class T, int LAYOUT, int VEC, int EPI, bool GATHER = false>
 __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmParams p) {
@@ -339,6 +341,12 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   stamp(p, 0, tid);
 
   // epilogue geometry: accumulator (col = lane&31, row = (r&3) + 8*(r>>2) + 4*h) -> LDS C image [rows][BN+4] -> float4 row pieces
+  // Only ONE tile carries the rarely used epilogue forms, so that they do not inflate (and push into scratch memory) every other
+  // instantiation: the element-wise path for outputs that cannot take float4 accesses (odd N / ldc, unaligned C: the host sends
+  // those to 64 x 64 x 32, pick_tile) and the fused LayerNorm of a 64-wide output row.
+  constexpr bool ELEMWISE = BM == 64 && BN == 64 && BK == 32;
+  constexpr bool LN_OK = EPI == EPI_STORE && BN == 64 && VEC == 4 && !GATHER && LAYOUT != GEMM_TN;
+  const bool evec = !ELEMWISE || p.evec;
   constexpr int CS = BN + 4;
   constexpr int NCHUNK = (BM * CS <= 2 * STAGE) ? 1 : T::WVM;   // whole tile at once, or one wave-row of the tile at a time
   constexpr int CROWS = BM / NCHUNK;
@@ -350,8 +358,8 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   // several thousand cycles under load, paid by every tile.
   // which epilogue (uniform over the launch except for split tiles): see "direct epilogue" below
   constexpr bool DIRECT_OK = LAYOUT != GEMM_TN && VEC == 4 && !GATHER && EPI != EPI_SPLITK && (BKC || TN <= 2);
-  const bool direct = DIRECT_OK && nz == 1 && p.evec && p.c_rgrp == 0 && p.res_mod == 0 && (EPI != EPI_GELU2 || p.ldc2 == p.ldc) && !(p.diag & 8) &&
-                      !p.ln_y;   // (the fused LayerNorm reduces over the 16 lanes that hold a row of the LDS image)
+  const bool direct = DIRECT_OK && nz == 1 && evec && p.c_rgrp == 0 && p.res_mod == 0 && (EPI != EPI_GELU2 || p.ldc2 == p.ldc) && !DIAG_BIT(p, 8) &&
+                      !(LN_OK && p.ln_y);   // (the fused LayerNorm reduces over the 16 lanes that hold a row of the LDS image)
   int dcol[TN];     // direct epilogue: this lane's column(s) inside the tile
   float dbias[TN];
 #pragma unroll
@@ -425,7 +433,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
     }
     __syncthreads();
     stamp(p, 1, tid);
-    if (p.diag & 1) __builtin_amdgcn_s_setprio(2);   // A/B knob: main-loop waves ahead of the prologue / epilogue waves they share a SIMD with
+    if (DIAG_BIT(p, 1)) __builtin_amdgcn_s_setprio(2);   // A/B knob: main-loop waves ahead of the prologue / epilogue waves they share a SIMD with
     for (int kt = 0; kt < nk; ++kt) {
       const float* la = smem + (kt & 1) * STAGE;
       const float* lb = la + A_TILE;
@@ -450,7 +458,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
       }
       __syncthreads();
     }
-    if (p.diag & 1) __builtin_amdgcn_s_setprio(0);
+    if (DIAG_BIT(p, 1)) __builtin_amdgcn_s_setprio(0);
   } else {
     FA::run(ra, p.A, p.lda, m0, p.M, kbeg, kend, tid);
     FB::run(rb, p.B, p.ldb, n0, p.N, kbeg, kend, tid);
@@ -481,7 +489,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   }
 
   stamp(p, 2, tid);
-  if (p.diag & 2) {   // diagnostic (dgvit_set_gemm_diagnostics(2)): main loop only - what would a free epilogue be worth?
+  if (DIAG_BIT(p, 2)) {   // diagnostic (dgvit_set_gemm_diagnostics(2)): main loop only - what would a free epilogue be worth?
     float sacc = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -583,7 +591,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
           }
         }
       stamp(p, 3, tid);
-      if (p.stamps) {
+      if (DIAG_STAMPS(p)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(p, 7, tid);
       }
@@ -600,7 +608,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   // The arithmetic and its order are those of layernorm_fwd_kernel (float4 partial sums, xor butterfly; the butterfly steps that kernel
   // takes over lanes holding nothing add zeros), so the result is bit-identical to running that kernel on C afterwards.
   auto ln_piece = [&](int m, const float (&v)[4]) {
-    if constexpr (EPI == EPI_STORE && BN <= 256) {
+    if constexpr (LN_OK) {
       float s = (v[0] + v[1]) + (v[2] + v[3]);
 #pragma unroll
       for (int o = C4 / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -629,7 +637,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
       if (p.res) {
         const long long rrow = p.res_mod > 0 ? (long long)(m % p.res_mod) + 1 : (long long)m;
         const float* rp = p.res + rrow * p.ldr + n;
-        if (p.evec) {
+        if (evec) {
           const float4 q = *reinterpret_cast<const float4*>(rp);
           v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
         } else {
@@ -652,7 +660,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
     } else if (EPI == EPI_DGELU || EPI == EPI_DRELU) {
       const float* ap = p.aux + (long long)m * p.ldaux + n;
       float a4[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.evec) {
+      if (evec) {
         const float4 q = *reinterpret_cast<const float4*>(ap);
         a4[0] = q.x; a4[1] = q.y; a4[2] = q.z; a4[3] = q.w;
       } else {
@@ -663,10 +671,10 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = EPI == EPI_DGELU ? v[e] * gelu_erf_grad(a4[e]) : (a4[e] > 0.f ? v[e] : 0.f);
     }
-    if (p.evec) {
+    if (evec) {
       *reinterpret_cast<float4*>(cptr) = make_float4(v[0], v[1], v[2], v[3]);
       if (EPI == EPI_GELU2) *reinterpret_cast<float4*>(p.C2 + (long long)m * p.ldc2 + n) = make_float4(w2[0], w2[1], w2[2], w2[3]);
-      if (EPI == EPI_STORE && p.ln_y) ln_piece(m, v);
+      if (LN_OK && p.ln_y) ln_piece(m, v);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -688,12 +696,15 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   constexpr int NP = CROWS / RPP;                       // row pieces per thread and chunk
   static_assert(CROWS % RPP == 0, "epilogue row pieces");
   constexpr bool HAS_SIDE = EPI == EPI_STORE || EPI == EPI_DGELU || EPI == EPI_DRELU;
-  constexpr bool SIDE_ALL = NCHUNK * NP <= 4;           // all chunks' side inputs fit in 16 registers: fetch them up front
-  const bool fast = p.evec && !slab;
+  constexpr bool SIDE_ALL = NCHUNK == 1 && NP <= 4;     // one chunk whose side inputs fit in 16 registers: fetch them before the C image barrier
+                                                        // (two-chunk tiles take the direct epilogue on the hot path; prefetching both chunks here spilled)
+  const bool fast = evec && !slab;
   const bool nvalid = n < p.N;
   const int nc = nvalid ? n : 0;
   const bool use_side = HAS_SIDE && (EPI == EPI_STORE ? p.res != nullptr : true);
   float4 side[HAS_SIDE ? (SIDE_ALL ? NCHUNK * NP : NP) : 1];
+#pragma unroll
+  for (auto& sv : side) sv = make_float4(0.f, 0.f, 0.f, 0.f);   // (defined on every path: undefined values here were spilled to scratch)
   auto load_side = [&](int ch, float4* dst) {
 #pragma unroll
     for (int it = 0; it < NP; ++it) {
@@ -754,13 +765,20 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
         for (int it = 0; it < NP; ++it)
           sd[it] = make_float4(gelu_erf_grad(sd[it].x), gelu_erf_grad(sd[it].y), gelu_erf_grad(sd[it].z), gelu_erf_grad(sd[it].w));
       }
-      float4 t[NP];
+      // one-chunk tiles read all their row pieces first; two-chunk tiles (whose hot path is the direct epilogue above) read them
+      // one by one: the batch of NP = 4 pieces beside 4 side inputs did not fit the register budget of 5 workgroups per CU
+      constexpr bool T_FIRST = NCHUNK == 1;
+      float4 t[T_FIRST ? NP : 1];
+      if constexpr (T_FIRST) {
 #pragma unroll
-      for (int it = 0; it < NP; ++it) t[it] = *reinterpret_cast<const float4*>(smem + (rr0 + it * RPP) * CS + cc);
+        for (int it = 0; it < NP; ++it) t[it] = *reinterpret_cast<const float4*>(smem + (rr0 + it * RPP) * CS + cc);
+      }
 #pragma unroll
       for (int it = 0; it < NP; ++it) {
         const int m = m0 + ch * CROWS + rr0 + it * RPP;
-        float v[4] = {t[it].x, t[it].y, t[it].z, t[it].w}, w2[4];
+        if constexpr (!T_FIRST) t[0] = *reinterpret_cast<const float4*>(smem + (rr0 + it * RPP) * CS + cc);
+        const float4 tv = t[T_FIRST ? it : 0];
+        float v[4] = {tv.x, tv.y, tv.z, tv.w}, w2[4];
         if (EPI == EPI_STORE) {
           if (use_side) { v[0] += sd[it].x; v[1] += sd[it].y; v[2] += sd[it].z; v[3] += sd[it].w; }   // same order as `finish`: residual, then bias
 #pragma unroll
@@ -783,18 +801,17 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
           long long crow = m;
           if (EPI == EPI_STORE && p.c_rgrp > 0) crow = (long long)m + m / p.c_rgrp + 1;
           int ncol = n;
-          if (p.diag & 4) {   // diagnostic: every tile stores over tile 0 (the same instructions, no HBM write stream; results garbage)
+          if (DIAG_BIT(p, 4)) {   // diagnostic: every tile stores over tile 0 (the same instructions, no HBM write stream; results garbage)
             crow = m - m0;
             ncol = cc;
           }
           *reinterpret_cast<float4*>(Cz + crow * p.ldc + ncol) = make_float4(v[0], v[1], v[2], v[3]);   // (non-temporal stores measured the same: +-1 %)
           if (EPI == EPI_GELU2) *reinterpret_cast<float4*>(p.C2 + crow * p.ldc2 + ncol) = make_float4(w2[0], w2[1], w2[2], w2[3]);
-          if (EPI == EPI_STORE && p.ln_y) ln_piece(m, v);
+          if (LN_OK && p.ln_y) ln_piece(m, v);
         }
       }
-    } else if (n < p.N) {
+    } else if (ELEMWISE && n < p.N) {
       // element-wise path (unaligned / odd-N callers): one piece at a time through `finish`
-#pragma unroll 4
       for (int it = 0; it < CROWS / RPP; ++it) {
         const int rr = rr0 + it * RPP;
         const int m = m0 + ch * CROWS + rr;
@@ -809,7 +826,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
     if (ch + 1 < NCHUNK) __syncthreads();
   }
   stamp(p, 3, tid);                                                 // stores issued
-  if (p.stamps) {
+  if (DIAG_STAMPS(p)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // diagnostic run only: the last stamp sees them drained
     stamp(p, 7, tid);
   }
@@ -914,6 +931,7 @@ __global__ void __launch_bounds__(256) reduce_slabs_scalar_kernel(const float* _
   else out2[i - n1] = s;
 }
 
+#ifdef DGVIT_DIAG   // measured 4-15 % slower than the per-tile kernel: kept for tools/ and its equality tests only
 // ---- pipelined persistent variant: one continuous k-tile stream per workgroup, a tile's stores under the next tile's MFMAs -----
 // What the per-tile kernel loses at the K = 256 shapes (45 % of the step's GEMM time) is its epilogue: with the stores skipped
 // (diagnostic bit of dgvit_set_gemm_diagnostics) QKV / fc1 / fc2-dgrad run at 133-135 TFLOP/s instead of 101-107
@@ -1198,12 +1216,13 @@ __global__ void __launch_bounds__(T::NT, T::LDS_BYTES * 4 <= 160 * 1024 ? 4 : 2)
 #pragma unroll
   for (int r = 0; r < 16; ++r) drain_row(r);
   stamp(p, 3, tid);
-  if (p.stamps) {
+  if (DIAG_STAMPS(p)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(p, 7, tid);
   }
 }
 
+#endif   // DGVIT_DIAG
 // ---- in-launch split-K policy -------------------------------------------------------------------------------------------
 // (a) few tiles, long K (small batches: T = 65 ... 2080 rows against K = 2048): every tile is cut so that the grid fills the chip;
 // (b) a big grid whose last partial round would leave most CUs idle (tiles mod 256 <= 128: measured at 25600 x 256 x 2048,
@@ -1240,6 +1259,7 @@ inline GemmSplitPlan split_plan(int M, int N, int K, int BM, int BN, int BK, int
   return pl;
 }
 
+#ifdef DGVIT_DIAG
 template <class T, int LAYOUT, int EPI>
 int launch_persistent(const GemmParams& p, hipStream_t stream, bool* taken) {
   *taken = false;
@@ -1284,6 +1304,7 @@ int launch_persistent(const GemmParams& p, hipStream_t stream, bool* taken) {
   }
   return DGVIT_OK;
 }
+#endif   // DGVIT_DIAG
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
@@ -1295,17 +1316,17 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
   constexpr int A_TILE = AKC ? BM * (BK + 4) : BK * (BM + 4);
   constexpr int B_TILE = BKC ? BN * (BK + 4) : BK * (BN + 4);
   constexpr size_t lds = 2 * (A_TILE + B_TILE) * sizeof(float);
-  static bool attr_done = false;
+  static DeviceOnce once;
   auto kern = gemm_f32_kernel<T, LAYOUT, VEC, EPI, GATHER>;
-  if (!attr_done) {
+  if (const unsigned long long bit = once.pending()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return dgvit_set_error(DGVIT_ERR_HIP, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_done = true;
+    once.mark(bit);
   }
   GemmParams p = p0;
   if (p.ln_y) {   // fused LayerNorm: the whole output row must sit in this tile's LDS image, vector path
-    DGVIT_CHECK_ARG(EPI == EPI_STORE && VEC == 4 && !GATHER && LAYOUT != GEMM_TN && p.evec && p.N == BN && p.c_rgrp == 0,
-                    "gemm: fused LayerNorm needs the vector EPI_STORE path and N == %d (the tile width), got N = %d", BN, p.N);
+    DGVIT_CHECK_ARG(EPI == EPI_STORE && VEC == 4 && !GATHER && LAYOUT != GEMM_TN && p.evec && p.N == BN && BN == 64 && p.c_rgrp == 0,
+                    "gemm: fused LayerNorm needs the vector EPI_STORE path, a 64-wide tile and N == 64, got tile width %d, N = %d", BN, p.N);
     DGVIT_CHECK_ARG(p.ln_g && p.ln_b && p.ln_mean && p.ln_rstd && p.ln_ld % 4 == 0 && al16(p.ln_g) && al16(p.ln_b) && al16(p.ln_y),
                     "gemm: fused LayerNorm operands must be present and 16-byte aligned");
   }
@@ -1325,6 +1346,7 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
       blocks = pl.split_from + (tiles - pl.split_from) * pl.nsplit;
     }
   }
+#ifdef DGVIT_DIAG
   if constexpr (VEC == 4 && !GATHER && EPI != EPI_SPLITK && LAYOUT != GEMM_TN) {
     // whole tiles only, vector epilogue, plain row mapping: the persistent kernel (tile loop in the workgroup, next tile's fetch
     // under the epilogue) when a resident slot gets several tiles
@@ -1335,6 +1357,7 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
       if (rc != DGVIT_OK || taken) return rc;
     }
   }
+#endif
   dim3 grid((unsigned)blocks, 1, (unsigned)nsplit);
   const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, stream);
   hipLaunchKernelGGL(kern, grid, dim3(T::NT), lds + (size_t)g_gemm_lds_pad, stream, p);
@@ -1344,7 +1367,7 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
 }
 
 // tile_hint = BM*1000000 + BN*1000 + BK (e.g. 128128032), 0 = automatic
-#define DGVIT_TILES(X) X(128, 128, 32) X(128, 128, 16) X(64, 64, 32) X(64, 64, 64) X(128, 64, 32) X(64, 128, 32) X(128, 64, 16) X(64, 128, 16) X(64, 64, 16)
+#define DGVIT_TILES(X) X(128, 128, 32) X(128, 128, 16) X(64, 64, 32) X(64, 64, 64) X(128, 64, 32) X(64, 128, 32) X(64, 128, 16) X(64, 64, 16)
 
 // measured on MI355X at T = 25600 token rows (tools/gemm_shapes_bench.py, profiles/r01_b_gemm_tiles.txt):
 // weight gradients (long K, split over tokens) like the 128x128 tile; forward / data-gradient GEMMs are
@@ -1364,6 +1387,7 @@ int pick_tile(const GemmParams& p, int nsplit, bool vec4, int tile_hint, hipStre
   if (choice == 64) choice = 64064032;
   if (choice == 128) choice = 128128032;
   if (choice == 0) choice = auto_tile(LAYOUT, p.M, p.N);
+  if (!p.evec) choice = 64064032;   // the one tile that carries the element-wise epilogue (odd N / ldc, unaligned outputs)
 #define X(BM_, BN_, BK_) \
   if (choice == BM_ * 1000000 + BN_ * 1000 + BK_) return launch<TileCfg<BM_, BN_, BK_>, LAYOUT, 4, EPI>(p, nsplit, stream);
   DGVIT_TILES(X)
@@ -1374,15 +1398,6 @@ int pick_tile(const GemmParams& p, int nsplit, bool vec4, int tile_hint, hipStre
 
 }  // namespace
 
-int g_gemm_tile_hint = 0;  // test/bench override: 0 auto, 64, 128
-int g_gemm_lds_pad = 0;    // diagnostic: extra dynamic LDS bytes per workgroup (caps the workgroups per CU: occupancy probe)
-long long* g_gemm_stamps = nullptr;   // diagnostic: per-workgroup clock stamps of the next launches (tools/gemm_stamps.py)
-int g_gemm_stamp_capacity = 0;
-int g_gemm_diag = 0;      // A/B knob: s_setprio 2 around the main loop of the per-tile kernel
-long long g_gemm_persist_launches = 0;   // launches that took the pipelined kernel (tests check that they exercise it)
-int g_gemm_persist_grid = 0;   // diagnostic: workgroups of the persistent launch (0 = resident slots)
-int g_gemm_persist = 0;        // 0 never (default: measured slower), 1 when a slot gets several tiles and nothing is split, 2 whenever eligible
-int g_gemm_split = 1;      // A/B knob: in-launch split-K of the forward / data-gradient GEMMs
 
 GemmSplitPlan gemm_split_plan(int layout, int M, int N, int K) {
   GemmSplitPlan none = {};

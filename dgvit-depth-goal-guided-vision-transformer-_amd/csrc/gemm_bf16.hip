@@ -25,10 +25,6 @@
 #include "bf16.h"
 #include "kernels.h"
 
-int g_gemm_bf16_tile_hint = 0;
-int g_gemm_bf16_group_m = 8;   // A/B knob: row panels per walk group of the persistent tile order
-int g_gemm_bf16_m16 = 1;   // the ring kernel issues v_mfma_f32_16x16x32_bf16 (default; 0 = 32x32x16: A/B knob dgvit_set_gemm_bf16_mfma16)
-long long* g_gemm_bf16_stamps = nullptr;   // diagnostic: see STAMP in gemm_bf16_ring_kernel
 
 namespace {
 
@@ -618,26 +614,36 @@ int num_cus() {
   return n;
 }
 
+// one ring-kernel instantiation: raise its dynamic-LDS limit on first use on this device, then launch it
+template <class T, int EPI, bool STAMP, bool TN, bool M16>
+int launch_ring(const GemmBf16Params& p, int grid, int vtiles, long long* stamps, hipStream_t st) {
+  constexpr int LDS = Ring<T, EPI>::LDS;
+  auto kern = gemm_bf16_ring_kernel<T, EPI, STAMP, TN, M16>;
+  static DeviceOnce once;
+  if (const unsigned long long bit = once.pending()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit to %d bytes", LDS);
+    once.mark(bit);
+  }
+  const int slot = STAMP ? -1 : profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, st);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, p, vtiles, stamps);
+  if (!STAMP) profile_end(slot, st);
+  DGVIT_CHECK_LAUNCH("gemm_bf16_ring_kernel");
+  return DGVIT_OK;
+}
+
 template <class T, int EPI, bool RING>
 int launch(const GemmBf16Params& p_in, hipStream_t st) {
   GemmBf16Params p = p_in;
   if (p.group_m <= 0) p.group_m = g_gemm_bf16_group_m > 0 ? g_gemm_bf16_group_m : 8;
   const long long tiles = (long long)((p.M + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN);
   DGVIT_CHECK_ARG(tiles < (1ll << 30), "gemm_bf16: too many tiles");
-  static bool attr_done = false;   // the kernels use more than the 64 KB default dynamic LDS limit
   if constexpr (RING) {
-    constexpr int LDS = Ring<T, EPI>::LDS;
     // tile-relative 32-bit buffer offsets in the epilogue
     DGVIT_CHECK_ARG((long long)(T::BM + T::BM / (p.c_rgrp > 0 ? p.c_rgrp : T::BM) + 2) * p.ldc * 4 < (1ll << 31) &&
                         (long long)(p.res_mod > 0 ? p.res_mod + 1 : T::BM) * p.ldr * 4 < (1ll << 31) &&
                         (long long)T::BM * p.ldc2 * 2 < (1ll << 31) && (long long)T::BM * p.ldaux * 2 < (1ll << 31),
                     "gemm_bf16: output leading dimension too large");
-    if (!attr_done) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              LDS) != hipSuccess)
-        return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit to %d bytes", LDS);
-      attr_done = true;
-    }
     DGVIT_CHECK_ARG(EPI != BEPI_GELU2_BF16 || (p.ldc2 == p.ldc && p.c_rgrp == 0), "gemm_bf16: the GELU epilogue with a pre-activation copy needs ldc2 == ldc");
     const int S = p.ksplit > 1 ? p.ksplit : 1;
     DGVIT_CHECK_ARG(S == 1 || (p.kchunk > 0 && p.kchunk % 32 == 0 && (long long)(S - 1) * p.kchunk < p.K && (long long)S * p.kchunk >= p.K),
@@ -646,61 +652,28 @@ int launch(const GemmBf16Params& p_in, hipStream_t st) {
     const long long vtiles = tiles * S;
     DGVIT_CHECK_ARG(vtiles < (1ll << 30), "gemm_bf16: too many tiles");
     const int grid = (int)(vtiles < num_cus() ? vtiles : num_cus());   // one persistent workgroup per CU
+#ifdef DGVIT_DIAG
     if constexpr (EPI == BEPI_BF16) {
-      if (g_gemm_bf16_stamps) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<T, EPI, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-          return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit");
-        hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI, true>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, g_gemm_bf16_stamps);
-        DGVIT_CHECK_LAUNCH("gemm_bf16_ring_kernel(stamps)");
-        return DGVIT_OK;
-      }
+      if (g_gemm_bf16_stamps) return launch_ring<T, EPI, true, false, false>(p, grid, (int)vtiles, g_gemm_bf16_stamps, st);
     }
+#endif
     if constexpr (EPI == BEPI_F32_PLAIN && T::BM == 256 && T::BN == 256) {
       if (p.tn) {   // contraction-major operands (weight gradients)
-        static bool tn_attr = false;
-        if (!tn_attr) {
-          if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<T, EPI, false, true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit");
-          tn_attr = true;
-        }
-        const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, st);
-        if (g_gemm_bf16_m16) {
-          static bool a16 = false;
-          if (!a16 && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<T, EPI, false, true, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit");
-          a16 = true;
-          hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI, false, true, true>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, (long long*)nullptr);
-        } else {
-          hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI, false, true>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, (long long*)nullptr);
-        }
-        profile_end(slot, st);
-        DGVIT_CHECK_LAUNCH("gemm_bf16_ring_kernel(TN)");
-        return DGVIT_OK;
+        KNOB_IF(g_gemm_bf16_m16) return launch_ring<T, EPI, false, true, true>(p, grid, (int)vtiles, nullptr, st);
+        else return launch_ring<T, EPI, false, true, false>(p, grid, (int)vtiles, nullptr, st);
       }
     }
     DGVIT_CHECK_ARG(!p.tn, "gemm_bf16: the TN layout needs the plain fp32 epilogue and the 256 x 256 tile");
-    const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, st);
-    if (g_gemm_bf16_m16) {
-      static bool a16 = false;
-      if (!a16 && hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_ring_kernel<T, EPI, false, false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-        return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit");
-      a16 = true;
-      hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI, false, false, true>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, (long long*)nullptr);
-    } else {
-      hipLaunchKernelGGL((gemm_bf16_ring_kernel<T, EPI>), dim3(grid), dim3(512), LDS, st, p, (int)vtiles, (long long*)nullptr);
-    }
-    profile_end(slot, st);
+    KNOB_IF(g_gemm_bf16_m16) return launch_ring<T, EPI, false, false, true>(p, grid, (int)vtiles, nullptr, st);
+    else return launch_ring<T, EPI, false, false, false>(p, grid, (int)vtiles, nullptr, st);
   } else {
     DGVIT_CHECK_ARG(p.ksplit <= 1 && !p.tn, "gemm_bf16: split-K / TN need the 256 x 256 tile");
-    if (!attr_done) {
+    static DeviceOnce once;
+    if (const unsigned long long bit = once.pending()) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<T, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               T::LDS) != hipSuccess)
         return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit to %d bytes", T::LDS);
-      attr_done = true;
+      once.mark(bit);
     }
     const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, st);
     hipLaunchKernelGGL((gemm_bf16_kernel<T, EPI>), dim3((unsigned)tiles), dim3(T::NT), T::LDS, st, p);
@@ -722,7 +695,9 @@ int dispatch(const GemmBf16Params& p, hipStream_t st) {
     case 256256: return launch<BTile<256, 256, 2, 4>, EPI, true>(p, st);
     case 256128: return launch<BTile<256, 128, 4, 2>, EPI, true>(p, st);
     case 128128: return launch<BTile<128, 128, 2, 2>, EPI, false>(p, st);
+#ifdef DGVIT_DIAG
     case 256254: return launch<BTile<256, 256, 2, 2>, EPI, false>(p, st);   // experiment: 4 waves of 128 x 128 (one per SIMD), per-tile kernel
+#endif
     default: return dgvit_set_error(DGVIT_ERR_ARG, "gemm_bf16: unknown tile %d", tile);
   }
 }

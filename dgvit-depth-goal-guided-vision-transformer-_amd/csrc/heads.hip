@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) mlp_head_bwd_kernel(const HeadArgs a) {
   }
   for (int f = tid; f < a.heads3 * HR * a.n3; f += 256) {
     const int o = f % a.n3, row = (f / a.n3) % HR, j = f / (a.n3 * HR);
-    const float* dyj = a.dyp[t][j];
+    const float* dyj = j ? a.dyp[t][1] : a.dyp[t][0];   // (a per-lane index into a kernel-argument array would go through scratch memory)
     dys[f] = (dyj && row0 + row < a.B) ? dyj[(long long)(row0 + row) * a.n3 + o] : 0.f;
   }
   __syncthreads();
@@ -198,8 +198,9 @@ __global__ void __launch_bounds__(256) mlp_head_bwd_kernel(const HeadArgs a) {
     const int c = f % (a.n2 + 1), o = (f / (a.n2 + 1)) % a.n3, j = f / ((a.n2 + 1) * a.n3);
     float s = 0.f;
     for (int r = 0; r < HR; ++r) s = fmaf(dys[(j * HR + r) * a.n3 + o], c < a.n2 ? h2s[r * S2 + c] : 1.f, s);
-    float* ow = !a.dyp[t][j] ? nullptr : a.direct ? a.dw3[t][j] : part + po.w3[j];     // an unused third layer gets no gradient
-    float* ob = !a.dyp[t][j] ? nullptr : a.direct ? a.db3[t][j] : part + po.b3[j];
+    const bool used = (j ? a.dyp[t][1] : a.dyp[t][0]) != nullptr;     // an unused third layer gets no gradient
+    float* ow = !used ? nullptr : a.direct ? (j ? a.dw3[t][1] : a.dw3[t][0]) : part + (j ? po.w3[1] : po.w3[0]);
+    float* ob = !used ? nullptr : a.direct ? (j ? a.db3[t][1] : a.db3[t][0]) : part + (j ? po.b3[1] : po.b3[0]);
     if (c < a.n2) { if (ow) ow[(long long)o * a.n2 + c] = s; }
     else if (ob) ob[o] = s;
   }
@@ -350,13 +351,13 @@ int mlp_head_forward(const dgvit_mlp_desc* d, const float* const* in, const floa
   DGVIT_CHECK_ARG(h1 && h2 && y, "mlp_head_forward: null output");
   a.h1 = h1; a.h2 = h2; a.y = y;
   const size_t lds = fwd_lds(a.KP, a.n1, a.n2);
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce once;
+  if (const unsigned long long bit = once.pending()) {
     const int mx = (int)fwd_lds(HMAXK, HMAXN, HMAXN);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_head_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_head_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
       return dgvit_set_error(DGVIT_ERR_HIP, "mlp_head_forward: hipFuncSetAttribute failed");
-    attr = true;
+    once.mark(bit);
   }
   const dim3 grid((a.B + HR - 1) / HR, a.towers);
   const int slot = profile_begin(PROF_OTHER, 0.0, stream);
@@ -401,13 +402,13 @@ int mlp_head_backward(const dgvit_mlp_desc* d, const float* const* in, const flo
   a.direct = nwg == 1;
   a.part = scratch; a.part_stride = po.total;
   const size_t lds = bwd_lds(a.KP, a.n1, a.n2, a.n3, a.heads3);
-  static bool attr = false;
-  if (!attr) {
+  static DeviceOnce once;
+  if (const unsigned long long bit = once.pending()) {
     const int mx = (int)bwd_lds(HMAXK, HMAXN, HMAXN, 4, 2);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_head_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_head_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, mx) != hipSuccess)
       return dgvit_set_error(DGVIT_ERR_HIP, "mlp_head_backward: hipFuncSetAttribute failed");
-    attr = true;
+    once.mark(bit);
   }
   // a twin head runs both towers in ONE launch (blockIdx.y): tower 0 writes dx, tower 1 writes its input gradient to scratch and a
   // small kernel adds it (x = t0 + t1: the order is fixed); the two towers used to be two launches one behind the other

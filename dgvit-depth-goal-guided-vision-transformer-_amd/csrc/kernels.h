@@ -14,7 +14,6 @@ int colsum_blocks(int T);
 int colsum(const float*, long long, float*, float*, int, int, int, hipStream_t);
 int attention_fwd(const float*, float*, float*, int, int, int, int, int, hipStream_t);
 int attention_bwd(const float*, const float*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
-void attention_bwd_single_pass(int on);
 int patchify(const float*, float*, int, int, int, int, int, hipStream_t);
 int goal_row(const float*, const float*, float*, int, int, int, hipStream_t);
 int dropout_inplace(float*, long long, unsigned long long, const unsigned long long*, float, hipStream_t);
@@ -34,15 +33,6 @@ long long depth_normalize_scratch_floats(int);
 int noise_clip(const float*, const float*, float*, long long, float, unsigned long long, hipStream_t);
 int gaussian_blur_band(const float*, float*, float*, int, int, int, int, int, int, hipStream_t);
 int resize_bilinear(const float*, float*, int, int, int, int, int, float, hipStream_t);
-extern int g_gemm_tile_hint;
-extern int g_gemm_split;
-extern int g_gemm_lds_pad;
-extern int g_gemm_persist;
-extern long long g_gemm_persist_launches;
-extern int g_gemm_diag;
-extern int g_gemm_persist_grid;
-extern long long* g_gemm_stamps;
-extern int g_gemm_stamp_capacity;
 int mlp_head_forward(const dgvit_mlp_desc*, const float* const*, const float* const*, float*, float*, float*, hipStream_t);
 long long mlp_head_backward_scratch(const dgvit_mlp_desc*);
 int mlp_head_backward(const dgvit_mlp_desc*, const float* const*, const float* const*, const float*, const float*, const float* const*,
@@ -51,6 +41,7 @@ int tanh_gaussian_forward(const float*, const float*, const float*, const float*
                           int, int, hipStream_t);
 int tanh_gaussian_backward(const float*, const float*, const float*, const float*, int, float, float, const float*, const float*,
                            const float*, float*, float*, int, int, hipStream_t);
+// (frame.hip: diagnostic build only)
 bool frame_path_supports(int B, int N, int D, int H, int dh, int M);
 long long frame_path_scratch_floats(int B, int N, int D, int H, int M);
 int frame_path_forward(const float* x0, const float* const* params, int L, float* scratch, float* feat, int B, int N, int D, int H, int dh,

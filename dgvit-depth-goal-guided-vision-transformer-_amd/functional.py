@@ -53,7 +53,7 @@ def _empty_batch(shape, tensors):
 
 def make_config(image, patch, dim, depth, heads, dim_head, mlp_dim) -> dgvit_config:
     return dgvit_config(int(image[0]), int(image[1]), int(patch[0]), int(patch[1]), int(dim), int(depth), int(heads),
-                        int(dim_head), int(mlp_dim), 0)
+                        int(dim_head), int(mlp_dim), 0, 0)
 
 
 # ------------------------------------------------------------------------------------------------ encoder

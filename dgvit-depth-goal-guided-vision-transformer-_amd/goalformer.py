@@ -119,7 +119,7 @@ class GoT(nn.Module):
         self.to_latent = nn.Identity()
         self.mlp_head = nn.Sequential(nn.LayerNorm(dim), nn.Linear(dim, num_classes))  # unused, kept for checkpoints
         self._cfg = (image_height, image_width, patch_height, patch_width, dim, depth, heads, dim_head, mlp_dim,
-                     1 if pool == 'mean' else 0)
+                     1 if pool == 'mean' else 0, 0)       # last entry: schedule flags (set_schedule)
         self.compute_dtype = torch.float32
         self._bf16_weights = F_.Bf16Weights()
         self.register_load_state_dict_post_hook(_weights_loaded)
@@ -143,6 +143,16 @@ class GoT(nn.Module):
         after any OTHER in-place write call ``freeze_bf16_weights()`` again (it drops the cached copies)."""
         self._bf16_weights.frozen = bool(frozen)
         self._bf16_weights.invalidate()
+        return self
+
+    def set_schedule(self, dense_last_block: bool = False, wgrad_overlap: bool = False):
+        """Per-module schedule options, passed to the C ABI with every call (``dgvit_config.flags``; nothing global).
+        ``dense_last_block``: run the whole last block instead of its token-0 rows only (identical results; A/B measurements).
+        ``wgrad_overlap``: the backward runs the weight-gradient GEMMs on a helper stream beside the data-gradient chain
+        (+3..5 % frames/s at BASELINE config 3; per-kernel timings stop being interpretable)."""
+        from ._lib import FLAG_DENSE_LAST_BLOCK, FLAG_WGRAD_OVERLAP
+        flags = (FLAG_DENSE_LAST_BLOCK if dense_last_block else 0) | (FLAG_WGRAD_OVERLAP if wgrad_overlap else 0)
+        self._cfg = (*self._cfg[:10], flags)
         return self
 
     def set_compute_dtype(self, dtype):

@@ -10,6 +10,9 @@
  *   - every pointer is a DEVICE pointer to a caller-allocated, contiguous fp32 buffer (row-major);
  *   - nothing allocates, frees or synchronises; all work is enqueued on `stream` (a hipStream_t passed
  *     as void*, 0 = the null stream); callable from any host thread (autograd's backward thread too);
+ *   - no mutable global state besides one-time initialisation (a helper stream, per-device kernel attributes): there are no
+ *     setter functions; the two schedule options are fields of dgvit_config (`flags`) and travel with every call.  The A/B and
+ *     diagnostic knobs of tools/ exist only in the separately built libdgvit_hip_diag.so (include/dgvit_hip_diag.h);
  *   - return value 0 = success, negative = error; dgvit_last_error() gives the thread-local message;
  *   - sizes are element counts unless a name says bytes.
  */
@@ -21,7 +24,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define DGVIT_ABI_VERSION 5
+#define DGVIT_ABI_VERSION 6
 
 /* error codes */
 #define DGVIT_OK 0
@@ -52,7 +55,17 @@ typedef struct dgvit_config {
   int dim_head;  /* dh, inner width I = H*dh */
   int mlp_dim;   /* M */
   int pool_mean; /* 0: pool='cls' (token 0, what the reference's networks use), 1: pool='mean' (GoalFormer.py:167) */
+  int flags;     /* schedule options, DGVIT_FLAG_* below (0 = defaults); a forward and its backward must be given the same value */
 } dgvit_config;
+/* The output reads only token 0 of the last block (GoalFormer.py:167), so by default that block computes Q, the attention output,
+ * to_out and the feed-forward for one row per frame (K / V for all) -- identical results, fewer FLOPs.  This flag runs the dense
+ * last block instead (A/B measurements; the bf16 training path is always dense). */
+#define DGVIT_FLAG_DENSE_LAST_BLOCK 1
+/* dgvit_got_backward runs the weight-gradient GEMMs on one internal helper stream (created on first use, ordered against the
+ * caller's stream with events only, so it is capturable) beside the data-gradient chain: +3..5 % frames/s at BASELINE config 3 on
+ * MI355X, but concurrent kernels stretch each other's durations, so per-kernel timings (dgvit_profile_*, rocprof) stop being
+ * interpretable.  Off: everything stays on the caller's stream. */
+#define DGVIT_FLAG_WGRAD_OVERLAP 2
 
 /* Parameter / gradient tables: arrays of DGVIT_NUM_GLOBAL_PARAMS + DGVIT_PARAMS_PER_LAYER*depth device
  * pointers in this order (reference state_dict key in brackets, prefix "trans."):
@@ -161,57 +174,6 @@ long long dgvit_gemm_scratch_floats(int layout, int M, int N, int K);
 int dgvit_gemm(int layout, int epilogue, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
                int N, int K, const float* bias, const float* res, int ldr, float* C2, int ldc2, const float* aux,
                int ldaux, float* scratch, long long scratch_floats, void* stream);
-/* test/bench knob: force the GEMM workgroup tile (0 = automatic; BM*1000000 + BN*1000 + BK, e.g. 128128032) */
-void dgvit_set_gemm_tile(int tile);
-/* The output reads only token 0 of the last block (GoalFormer.py:167), so by default that block computes Q,
- * attention output, to_out and the feed-forward for one row per frame (K/V for all) -- identical results, fewer
- * FLOPs.  0 switches this off (dense last block, for A/B measurements). */
-void dgvit_set_prune_last_layer(int on);
-/* Opt-in (default 0): dgvit_got_backward runs the weight-gradient GEMMs on one internal helper stream (created on
- * first use, ordered against the caller's stream with events only, so it is capturable) to overlap them with the
- * data-gradient chain: +5 % frames/s at C3 on MI355X, but concurrent kernels stretch each other's durations, so
- * per-kernel timings (dgvit_profile_*, rocprof) stop being interpretable.  0 keeps everything on the caller's stream. */
-void dgvit_set_wgrad_overlap(int on);
-/* A/B knob (default 1): dgvit_got_backward sums a layer's split-K weight-gradient slabs and LayerNorm partials in ONE grouped
- * launch per layer; 0 = one reduction launch behind every producer (the round-1 schedule).  Results are bit-identical. */
-void dgvit_set_grouped_reduce(int on);
-/* A/B knob (default 1): forward / data-gradient GEMMs with far fewer output tiles than the chip has workgroup slots, or with a
- * nearly empty last round of tiles, are split over K inside the launch (partial tiles + last-arriver epilogue, deterministic).
- * 0 = one workgroup per output tile.  Results agree to fp32 rounding (the order of the k-sum changes). */
-void dgvit_set_gemm_split(int on);
-/* A/B knob: 1 (default) for dim == 64 the encoder forward runs its LayerNorms inside the epilogues of the GEMMs that produce their
- * inputs (to_out -> LN2, fc2 -> the next block's LN1); 0 = separate LayerNorm launches.  Bit-identical results. */
-void dgvit_set_ln_fusion(int on);
-/* A/B knob: 1 (default) dgvit_cnn_forward runs conv2 / conv3 as implicit GEMMs (5x5xC windows gathered by the GEMM's A-tile loader);
- * 0 = im2col + GEMM.  Bit-identical results. */
-void dgvit_set_conv_gather(int on);
-/* diagnostic: request `bytes` more dynamic LDS per fp32 GEMM workgroup than it uses (caps the workgroups per CU: occupancy probes) */
-void dgvit_set_gemm_lds_pad(int bytes);
-/* Diagnostics of the per-tile fp32 GEMM (tools only; default 0).  Bit 0: A/B knob, raise the wave priority (s_setprio 2) of the main
- * loop over the prologue / epilogue waves on the same SIMD (measured: no effect).  Bits 1 and 2 are TIMING diagnostics whose results are
- * garbage: bit 1 - the kernel returns after the main loop without writing C; bit 2 - every tile stores over tile 0 (the same epilogue
- * instructions and side reads, no write stream to HBM; LDS-image epilogue only).  Bit 3: A/B knob, use the LDS-image epilogue where the
- * direct (register) epilogue would be taken.  DESIGN.md 3.9 uses them to take the epilogue's cost apart. */
-void dgvit_set_gemm_diagnostics(int bits);
-/* The pipelined persistent fp32 GEMM (one k-tile stream per workgroup across its tiles, a tile's stores under the next tile's main
- * loop; NT / NN forms, 16-byte-aligned operands, K = 16 k-tiles of the chosen tile: 256 at 16-deep, 512 at 32-deep k-tiles).
- * mode 0 = never, 1 = when a resident workgroup slot gets at least two tiles and no tile is split, 2 = whenever the launch is
- * eligible.  workgroups > 0 overrides the grid (diagnostic; 0 = automatic).  Same results bit for bit as the per-tile kernel: the
- * k order of a tile does not change. */
-void dgvit_set_gemm_persistent(int mode, int workgroups);
-/* launches that took the pipelined kernel since the library was loaded (tests check that they exercise it) */
-long long dgvit_gemm_persistent_launches(void);
-/* diagnostic (tools/gemm_stamps.py): non-NULL = every fp32 GEMM launch writes 16 int64 per workgroup (< `workgroups`) into the
- * device buffer: [0..3] shader clock at kernel start / first k-tile in LDS / main loop done / stores issued, [7] stores drained (the
- * stamped run waits for them), [4] and [6] the 100 MHz counter at start and end, [5] HW_ID | XCC_ID << 32, [8 + 2c] / [9 + 2c] epilogue chunk c: C image in
- * LDS / stores issued.  NULL (default) = off; the product never sets it. */
-void dgvit_set_gemm_stamps(long long* stamps, int workgroups);
-/* Opt-in experiment (default OFF): dgvit_got_forward with save_for_backward == 0 and at most max_rows token rows (default
- * 4160 = 64 frames of 65 tokens) runs every transformer block as TWO launches (one workgroup per frame and head; one per
- * frame and 128-wide hidden chunk) instead of seven GEMM / LayerNorm / attention launches -- aimed at SAC.choose_action
- * (DRL.py:170-185).  Correct (parity-tested) but measured slower than the split-K GEMM schedule on MI355X: each workgroup
- * walks five dependent phases of L2 round trips, see DESIGN.md 3.7. */
-void dgvit_set_small_batch_path(int on, int max_rows);
 
 /* nn.LayerNorm(D), eps 1e-5 (GoalFormer.py:34,37): y, and the per-row mean / rstd saved for backward */
 int dgvit_layernorm_forward(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
@@ -343,21 +305,6 @@ int dgvit_cast_f32_bf16(const float* src, unsigned short* dst, long long n, void
 int dgvit_gemm_bf16(int epilogue, const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, int M,
                     int N, int K, const float* bias, const float* res, int ldr, unsigned short* C2, int ldc2,
                     const unsigned short* aux, int ldaux, void* stream);
-/* test/bench knob: force the bf16 GEMM workgroup tile (0 = automatic; 256256, 256128, 128128; 256254 = probe: per-tile kernel with
- * 4 waves of 128 x 128, profiles/r02_e_bf16_gemm_4wave_128x128_probe.txt) */
-void dgvit_set_gemm_bf16_tile(int tile);
-/* test/bench knob: row panels per walk group of the persistent bf16 GEMM's tile order (default 8) */
-void dgvit_set_gemm_bf16_group_m(int rows);
-/* A/B knob: 1 (default) the single-pass fp32 attention backward for 32 < N <= 64 (every tile pair computed once); 0 the two-phase
- * kernel for every shape.  Same results up to summation order. */
-void dgvit_set_attention_bwd_single_pass(int on);
-/* A/B knob: which MFMA the ring GEMM issues: 1 (default) v_mfma_f32_16x16x32_bf16, 0 v_mfma_f32_32x32x16_bf16 (same cycles per
- * FLOP; the kernel runs under the chip's power limit and the 16x16 shape measured 2-3 % faster; same results up to summation order) */
-void dgvit_set_gemm_bf16_mfma16(int on);
-/* diagnostic (tools/bf16_stamps.py): non-NULL = the epilogue-0 ring GEMM runs its stamped build and writes, per workgroup,
- * 2 wave groups x 8 tiles x 4 int64 {s_memtime at tile start / after its main loop / after its epilogue, s_memrealtime}
- * to this device buffer (256 workgroups at most); NULL (default) = shipped kernels, no stamp executes. */
-void dgvit_set_gemm_bf16_stamps(long long* stamps);
 /* LayerNorm with fp32 input and bf16 output (mean / rstd may be NULL) */
 int dgvit_layernorm_forward_bf16(const float* x, const float* gamma, const float* beta, unsigned short* y, float* mean,
                                  float* rstd, int rows, int D, void* stream);

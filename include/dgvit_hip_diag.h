@@ -1,0 +1,80 @@
+/* libdgvit_hip_diag.so -- the diagnostic build of the DGViT library (tools/, A/B equality tests).
+ *
+ * Built from the same sources as libdgvit_hip.so with -DDGVIT_DIAG.  It exports everything include/dgvit_hip.h declares plus the
+ * knobs below, which are plain process-global variables (NOT thread-safe: set them from the thread that makes the calls, between
+ * steps), and it contains the code those knobs switch to: clock stamps and timing diagnostics inside the GEMM kernels, the
+ * pipelined persistent fp32 GEMM, the per-frame inference path, the 32x32x16 MFMA form of the bf16 ring GEMM.  The product
+ * library has none of this: there every knob is a compile-time constant with the default named here.
+ */
+#ifndef DGVIT_HIP_DIAG_H
+#define DGVIT_HIP_DIAG_H
+#include "dgvit_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+/* test/bench knob: force the GEMM workgroup tile (0 = automatic; BM*1000000 + BN*1000 + BK, e.g. 128128032) */
+void dgvit_set_gemm_tile(int tile);
+/* A/B knob (default 1): dgvit_got_backward sums a layer's split-K weight-gradient slabs and LayerNorm partials in ONE grouped
+ * launch per layer; 0 = one reduction launch behind every producer (the round-1 schedule).  Results are bit-identical. */
+void dgvit_set_grouped_reduce(int on);
+/* A/B knob (default 1): forward / data-gradient GEMMs with far fewer output tiles than the chip has workgroup slots, or with a
+ * nearly empty last round of tiles, are split over K inside the launch (partial tiles + last-arriver epilogue, deterministic).
+ * 0 = one workgroup per output tile.  Results agree to fp32 rounding (the order of the k-sum changes). */
+void dgvit_set_gemm_split(int on);
+/* A/B knob: 1 (default) for dim == 64 the encoder forward runs its LayerNorms inside the epilogues of the GEMMs that produce their
+ * inputs (to_out -> LN2, fc2 -> the next block's LN1); 0 = separate LayerNorm launches.  Bit-identical results. */
+void dgvit_set_ln_fusion(int on);
+/* A/B knob: 1 (default) dgvit_cnn_forward runs conv2 / conv3 as implicit GEMMs (5x5xC windows gathered by the GEMM's A-tile loader);
+ * 0 = im2col + GEMM.  Bit-identical results. */
+void dgvit_set_conv_gather(int on);
+/* diagnostic: request `bytes` more dynamic LDS per fp32 GEMM workgroup than it uses (caps the workgroups per CU: occupancy probes) */
+void dgvit_set_gemm_lds_pad(int bytes);
+/* Diagnostics of the per-tile fp32 GEMM (tools only; default 0).  Bit 0: A/B knob, raise the wave priority (s_setprio 2) of the main
+ * loop over the prologue / epilogue waves on the same SIMD (measured: no effect).  Bits 1 and 2 are TIMING diagnostics whose results are
+ * garbage: bit 1 - the kernel returns after the main loop without writing C; bit 2 - every tile stores over tile 0 (the same epilogue
+ * instructions and side reads, no write stream to HBM; LDS-image epilogue only).  Bit 3: A/B knob, use the LDS-image epilogue where the
+ * direct (register) epilogue would be taken.  DESIGN.md 3.9 uses them to take the epilogue's cost apart. */
+void dgvit_set_gemm_diagnostics(int bits);
+/* The pipelined persistent fp32 GEMM (one k-tile stream per workgroup across its tiles, a tile's stores under the next tile's main
+ * loop; NT / NN forms, 16-byte-aligned operands, K = 16 k-tiles of the chosen tile: 256 at 16-deep, 512 at 32-deep k-tiles).
+ * mode 0 = never, 1 = when a resident workgroup slot gets at least two tiles and no tile is split, 2 = whenever the launch is
+ * eligible.  workgroups > 0 overrides the grid (diagnostic; 0 = automatic).  Same results bit for bit as the per-tile kernel: the
+ * k order of a tile does not change. */
+void dgvit_set_gemm_persistent(int mode, int workgroups);
+/* launches that took the pipelined kernel since the library was loaded (tests check that they exercise it) */
+long long dgvit_gemm_persistent_launches(void);
+/* diagnostic (tools/gemm_stamps.py): non-NULL = every fp32 GEMM launch writes 16 int64 per workgroup (< `workgroups`) into the
+ * device buffer: [0..3] shader clock at kernel start / first k-tile in LDS / main loop done / stores issued, [7] stores drained (the
+ * stamped run waits for them), [4] and [6] the 100 MHz counter at start and end, [5] HW_ID | XCC_ID << 32, [8 + 2c] / [9 + 2c] epilogue chunk c: C image in
+ * LDS / stores issued.  NULL (default) = off; the product never sets it. */
+void dgvit_set_gemm_stamps(long long* stamps, int workgroups);
+/* Opt-in experiment (default OFF): dgvit_got_forward with save_for_backward == 0 and at most max_rows token rows (default
+ * 4160 = 64 frames of 65 tokens) runs every transformer block as TWO launches (one workgroup per frame and head; one per
+ * frame and 128-wide hidden chunk) instead of seven GEMM / LayerNorm / attention launches -- aimed at SAC.choose_action
+ * (DRL.py:170-185).  Correct (parity-tested) but measured slower than the split-K GEMM schedule on MI355X: each workgroup
+ * walks five dependent phases of L2 round trips, see DESIGN.md 3.7. */
+void dgvit_set_small_batch_path(int on, int max_rows);
+/* test/bench knob: force the bf16 GEMM workgroup tile (0 = automatic; 256256, 256128, 128128; 256254 = probe: per-tile kernel with
+ * 4 waves of 128 x 128, profiles/r02_e_bf16_gemm_4wave_128x128_probe.txt) */
+void dgvit_set_gemm_bf16_tile(int tile);
+/* test/bench knob: row panels per walk group of the persistent bf16 GEMM's tile order (default 8) */
+void dgvit_set_gemm_bf16_group_m(int rows);
+/* A/B knob: 1 (default) the single-pass fp32 attention backward for 32 < N <= 64 (every tile pair computed once); 0 the two-phase
+ * kernel for every shape.  Same results up to summation order. */
+void dgvit_set_attention_bwd_single_pass(int on);
+/* A/B knob: which MFMA the ring GEMM issues: 1 (default) v_mfma_f32_16x16x32_bf16, 0 v_mfma_f32_32x32x16_bf16 (same cycles per
+ * FLOP; the kernel runs under the chip's power limit and the 16x16 shape measured 2-3 % faster; same results up to summation order) */
+void dgvit_set_gemm_bf16_mfma16(int on);
+/* diagnostic (tools/bf16_stamps.py): non-NULL = the epilogue-0 ring GEMM runs its stamped build and writes, per workgroup,
+ * 2 wave groups x 8 tiles x 4 int64 {s_memtime at tile start / after its main loop / after its epilogue, s_memrealtime}
+ * to this device buffer (256 workgroups at most); NULL (default) = shipped kernels, no stamp executes. */
+void dgvit_set_gemm_bf16_stamps(long long* stamps);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGVIT_HIP_DIAG_H */

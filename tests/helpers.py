@@ -13,6 +13,41 @@ from oracle import dgvit_oracle as O  # noqa: E402  (tests are allowed to import
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+import contextlib  # noqa: E402
+
+# A/B knobs of libdgvit_hip_diag.so (include/dgvit_hip_diag.h): name -> (setter, default arguments)
+_KNOBS = {
+    "gemm_tile": ("dgvit_set_gemm_tile", (0,)), "gemm_split": ("dgvit_set_gemm_split", (1,)), "ln_fusion": ("dgvit_set_ln_fusion", (1,)),
+    "conv_gather": ("dgvit_set_conv_gather", (1,)), "grouped_reduce": ("dgvit_set_grouped_reduce", (1,)),
+    "gemm_diagnostics": ("dgvit_set_gemm_diagnostics", (0,)), "gemm_persistent": ("dgvit_set_gemm_persistent", (0, 0)),
+    "small_batch_path": ("dgvit_set_small_batch_path", (0, 0)), "gemm_bf16_tile": ("dgvit_set_gemm_bf16_tile", (0,)),
+    "gemm_bf16_mfma16": ("dgvit_set_gemm_bf16_mfma16", (1,)), "gemm_bf16_group_m": ("dgvit_set_gemm_bf16_group_m", (8,)),
+    "attention_bwd_single_pass": ("dgvit_set_attention_bwd_single_pass", (1,)), "gemm_lds_pad": ("dgvit_set_gemm_lds_pad", (0,)),
+}
+
+
+@contextlib.contextmanager
+def knobs(force_diag=False, **kw):
+    """Run a block with A/B knobs set.  The product library has no knobs: when every requested value is the shipped default the
+    block runs on libdgvit_hip.so itself; otherwise the package is routed through libdgvit_hip_diag.so (same sources, -DDGVIT_DIAG)
+    for the duration, the knobs are set there and put back afterwards.  Yields the active library."""
+    import dgvit_amd
+    want = {k: (v if isinstance(v, tuple) else (v,)) for k, v in kw.items()}
+    for k in want:
+        assert k in _KNOBS, k
+    changed = {k: v for k, v in want.items() if tuple(int(x) for x in v) != _KNOBS[k][1]}
+    if not changed and not force_diag:
+        yield dgvit_amd.load_library()
+        return
+    with dgvit_amd.diagnostic_library() as lib:
+        try:
+            for k, v in changed.items():
+                getattr(lib, _KNOBS[k][0])(*v)
+            yield lib
+        finally:
+            for k in changed:
+                getattr(lib, _KNOBS[k][0])(*_KNOBS[k][1])
+
 
 def load_fixture(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)

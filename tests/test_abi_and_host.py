@@ -10,6 +10,7 @@ import torch
 from helpers import O, ROOT
 
 HEADER = os.path.join(ROOT, "include", "dgvit_hip.h")
+DIAG_HEADER = os.path.join(ROOT, "include", "dgvit_hip_diag.h")
 
 
 @pytest.fixture(scope="module")
@@ -20,8 +21,8 @@ def amd():
     return dgvit_amd
 
 
-def _header_functions():
-    text = open(HEADER).read()
+def _header_functions(path=HEADER):
+    text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"\b(dgvit_[a-z0-9_]+)\s*\(", text)
     return sorted(set(n for n in names if n != "dgvit_config"))
@@ -36,13 +37,41 @@ def test_library_exports_every_header_symbol(amd):
         assert hasattr(lib, name), f"libdgvit_hip.so does not export {name}"
         assert name in _lib.SIGNATURES, f"ctypes binding has no signature for {name}"
     assert sorted(_lib.SIGNATURES) == declared, "binding and header disagree"
-    assert lib.dgvit_abi_version() == 5
+    assert lib.dgvit_abi_version() == 6
+    # the product library has no setters and none of the diagnostic entry points
+    assert not [n for n in declared if n.startswith("dgvit_set_")]
+    for name in _header_functions(DIAG_HEADER):
+        assert not hasattr(lib, name), f"libdgvit_hip.so exports the diagnostic entry point {name}"
+
+
+def test_diagnostic_library_exports_both_headers(amd):
+    from dgvit_amd import _lib
+    extra = _header_functions(DIAG_HEADER)
+    assert sorted(_lib.DIAG_SIGNATURES) == extra and len(extra) >= 10, "diagnostic binding and header disagree"
+    with amd.diagnostic_library() as dlib:
+        for name in _header_functions() + extra:
+            assert hasattr(dlib, name), f"libdgvit_hip_diag.so does not export {name}"
+        assert _lib.load() is dlib
+    assert _lib.load() is amd.load_library() and _lib.load() is not dlib
+
+
+def test_product_kernels_do_not_spill(amd):
+    """build.py's register audit: no product kernel uses scratch memory or spills VGPRs (the build fails otherwise; this re-reads
+    the per-kernel figures the compiler reported)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dgvit_build", os.path.join(ROOT, "dgvit-depth-goal-guided-vision-transformer-_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    kernels, bad = b.audit()
+    assert len(kernels) > 100 and not bad, [k["name"] for k in bad]
+    assert not b.SPILL_ALLOW
+    assert not any("pipe_kernel" in k["name"] or "frame_" in k["name"] for k in kernels), "experiments leaked into the product library"
 
 
 def test_size_queries_and_validation_without_gpu(amd):
     from dgvit_amd._lib import dgvit_config
     lib = amd.load_library()
-    cfg = dgvit_config(84, 84, 12, 12, 256, 6, 8, 64, 2048)
+    cfg = dgvit_config(84, 84, 12, 12, 256, 6, 8, 64, 2048)   # (pool_mean and flags default to 0)
     train = lib.dgvit_got_workspace_floats(ctypes.byref(cfg), 512, 1)
     infer = lib.dgvit_got_workspace_floats(ctypes.byref(cfg), 512, 0)
     assert train > infer > 0

@@ -13,7 +13,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import O, load_fixture, fixture_cfg  # noqa: E402
+from helpers import O, load_fixture, fixture_cfg, knobs  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -27,11 +27,8 @@ def F():
 @pytest.fixture(params=[0, 1], ids=["mfma32x32x16", "mfma16x16x32"])
 def mfma16(request):
     """both MFMA shapes of the ring GEMM (A/B knob dgvit_set_gemm_bf16_mfma16), restored afterwards"""
-    import dgvit_amd
-    lib = dgvit_amd.load_library()
-    lib.dgvit_set_gemm_bf16_mfma16(request.param)
-    yield request.param
-    lib.dgvit_set_gemm_bf16_mfma16(1)
+    with knobs(gemm_bf16_mfma16=request.param):      # 1 = the shipped form: runs on the product library
+        yield request.param
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -69,27 +66,17 @@ GEMM_SHAPES = [(256, 256, 64), (512, 768, 768), (200, 136, 104), (50, 64, 256), 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_bf16_f32_out_bias_residual(F, mfma16, M, N, K, tile):
     """fp32 output = exact products of bf16 operands summed in fp32: error is accumulation only"""
-    import dgvit_amd
-    lib = dgvit_amd.load_library()
     a, b, bias, res = rb(rnd(M, K, seed=1)), rb(rnd(N, K, seed=2)), rnd(N, seed=3).float().double(), rnd(M, N, seed=4).float().double()
-    lib.dgvit_set_gemm_bf16_tile(tile)
-    try:
+    with knobs(gemm_bf16_tile=tile):
         y = F.op_gemm_bf16(2, dbf(a), dbf(b), bias=bias.float().cuda(), res=res.float().cuda())
-    finally:
-        lib.dgvit_set_gemm_bf16_tile(0)
     close(y, a @ b.T + bias + res, atol=2e-5 * K ** 0.5 + 1e-5 * K ** 0.5 * 8, msg=f"{M}x{N}x{K} tile {tile}")
 
 
 @pytest.mark.parametrize("tile", [0, 256256, 256128])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (200, 136, 104), (591, 2304, 768), (37, 132, 264), (5000, 1540, 72)])
 def test_gemm_bf16_bf16_out_and_gelu(F, mfma16, M, N, K, tile):
-    import dgvit_amd
-    lib = dgvit_amd.load_library()
-    lib.dgvit_set_gemm_bf16_tile(tile)
-    try:
+    with knobs(gemm_bf16_tile=tile):
         _gemm_bf16_outputs(F, M, N, K)
-    finally:
-        lib.dgvit_set_gemm_bf16_tile(0)
 
 
 def _gemm_bf16_outputs(F, M, N, K):
@@ -113,17 +100,12 @@ def _gemm_bf16_outputs(F, M, N, K):
 
 def test_gemm_bf16_identity_asymmetric(F, mfma16):
     """A = I with an asymmetric integer B catches any row/column or k-order mix-up exactly"""
-    import dgvit_amd
-    lib = dgvit_amd.load_library()
     n = 512
     a = torch.eye(n, dtype=torch.float64)
     b = (torch.arange(n, dtype=torch.float64)[:, None] * 3 + torch.arange(n, dtype=torch.float64)[None, :] % 7) % 251
     for tile in (0, 256256, 256128):
-        lib.dgvit_set_gemm_bf16_tile(tile)
-        try:
+        with knobs(gemm_bf16_tile=tile):
             y = F.op_gemm_bf16(4, dbf(a), dbf(b))
-        finally:
-            lib.dgvit_set_gemm_bf16_tile(0)
         assert torch.equal(y.cpu().double(), b.T.contiguous()), tile
     # TN form: dW = A^T B with A = I picks out B
     dw = F.op_wgrad_bf16(dbf(a), dbf(b), want_bias=False)
@@ -190,17 +172,12 @@ def test_attention_bwd_bf16(F, B, N, H):
 # ---------------------------------------------------------------------------------------------- encoder
 def _run_encoder(cfg, params, img, goal, prune=True):
     import dgvit_amd
-    lib = dgvit_amd.load_library()
     m = dgvit_amd.GoT(image_size=cfg.image, patch_size=cfg.patch, num_classes=2, dim=cfg.dim, depth=cfg.depth, heads=cfg.heads,
                       mlp_dim=cfg.mlp_dim, dim_head=cfg.dim_head, channels=1)
     m.load_state_dict(params, strict=True)
-    m = m.cuda().eval().set_compute_dtype(torch.bfloat16)
-    lib.dgvit_set_prune_last_layer(1 if prune else 0)
-    try:
-        with torch.no_grad():
-            return m(img.cuda(), goal.cuda()).cpu()
-    finally:
-        lib.dgvit_set_prune_last_layer(1)
+    m = m.cuda().eval().set_compute_dtype(torch.bfloat16).set_schedule(dense_last_block=not prune)
+    with torch.no_grad():
+        return m(img.cuda(), goal.cuda()).cpu()
 
 
 @pytest.mark.parametrize("name", ["got_c5_l2_bf16", "got_c5_l12_bf16", "got_84p12_bf16"])

@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import O  # noqa: E402
+from helpers import O, knobs  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -40,28 +40,18 @@ GEMM_SHAPES = [(128, 128, 32), (256, 384, 64), (200, 136, 100), (50, 64, 256), (
 @pytest.mark.parametrize("tile", [0, 64, 128])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_nt_bias_residual(F, M, N, K, tile):
-    import dgvit_amd
-    lib = dgvit_amd.load_library()
     x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
-    lib.dgvit_set_gemm_tile(tile)
-    try:
+    with knobs(gemm_tile=tile):
         y = F.op_gemm(0, 0, dev(x), dev(w), M, N, K, bias=dev(b), res=dev(r))
-    finally:
-        lib.dgvit_set_gemm_tile(0)
     close(y, x @ w.T + b + r, atol=2e-4 * math.sqrt(K), msg=f"NT {M}x{N}x{K}")
 
 
 @pytest.mark.parametrize("tile", [0, 64])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_nn(F, M, N, K, tile):
-    import dgvit_amd
-    lib = dgvit_amd.load_library()
     a, b = rnd(M, K, seed=5), rnd(K, N, seed=6)
-    lib.dgvit_set_gemm_tile(tile)
-    try:
+    with knobs(gemm_tile=tile):
         y = F.op_gemm(1, 0, dev(a), dev(b), M, N, K)
-    finally:
-        lib.dgvit_set_gemm_tile(0)
     close(y, a @ b, atol=2e-4 * math.sqrt(K))
 
 

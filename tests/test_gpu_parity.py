@@ -208,8 +208,7 @@ def test_full_size_properties(amd):
 
 def test_last_block_token0_schedule_equals_dense(amd):
     """The last block computes Q / attention / to_out / feed-forward for token 0 only (GoalFormer.py:167 reads
-    x[:, 0]); outputs and every gradient must equal the dense schedule (dgvit_set_prune_last_layer(0))."""
-    lib = amd.load_library()
+    x[:, 0]); outputs and every gradient must equal the dense schedule (DGVIT_FLAG_DENSE_LAST_BLOCK, GoT.set_schedule)."""
     cfg = O.GoTConfig(image=(84, 84), patch=(12, 12), dim=256, depth=3, heads=8)
     params = O.make_params(O.policy_param_spec(cfg), 31)
     m = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, image_size=cfg.image, patch_size=cfg.patch), params).eval().to("cuda")
@@ -221,11 +220,9 @@ def test_last_block_token0_schedule_equals_dense(amd):
         ((mean ** 2).mean() + (log_std ** 2).mean()).backward()
         return mean.detach().clone(), log_std.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
 
-    try:
-        lib.dgvit_set_prune_last_layer(0)
-        md, ld, gd = run()
-    finally:
-        lib.dgvit_set_prune_last_layer(1)
+    m.trans.set_schedule(dense_last_block=True)
+    md, ld, gd = run()
+    m.trans.set_schedule(dense_last_block=False)
     mp_, lp_, gp_ = run()
     np.testing.assert_allclose(mp_.cpu().numpy(), md.cpu().numpy(), rtol=0, atol=2e-6)
     np.testing.assert_allclose(lp_.cpu().numpy(), ld.cpu().numpy(), rtol=0, atol=2e-6)
@@ -238,7 +235,6 @@ def test_last_block_token0_schedule_equals_dense(amd):
 def test_wgrad_helper_stream_equals_single_stream(amd):
     """Opt-in overlap of weight-gradient GEMMs on the helper stream must not change any gradient (ordering is
     event based); run twice to exercise event-ring reuse."""
-    lib = amd.load_library()
     cfg = O.GoTConfig(image=(84, 84), patch=(12, 12), dim=256, depth=3, heads=8)
     m = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, image_size=cfg.image, patch_size=cfg.patch),
                     O.make_params(O.policy_param_spec(cfg), 41)).eval().to("cuda")
@@ -252,14 +248,11 @@ def test_wgrad_helper_stream_equals_single_stream(amd):
         return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
 
     ref = run()
-    try:
-        lib.dgvit_set_wgrad_overlap(1)
-        for _ in range(3):
-            got = run()
-            for k in ref:
-                assert torch.equal(ref[k], got[k]), k   # same kernels, same order of summation: bit identical
-    finally:
-        lib.dgvit_set_wgrad_overlap(0)
+    m.trans.set_schedule(wgrad_overlap=True)
+    for _ in range(3):
+        got = run()
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), k   # same kernels, same order of summation: bit identical
 
 
 def test_flat_adam_matches_torch_adam(amd):

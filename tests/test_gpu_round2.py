@@ -15,7 +15,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from helpers import O, load_fixture, fixture_cfg  # noqa: E402
+from helpers import O, load_fixture, fixture_cfg, knobs  # noqa: E402
 
 OUT_TOL = 1e-4
 
@@ -589,11 +589,8 @@ def test_gemm_in_launch_split_k(amd, layout, epi, M, N, K):
     run = lambda: F.op_gemm(layout, epi, A, B, M, N, K, bias=bias, res=res, aux=aux)
     y1, y2 = run(), run()
     assert torch.equal(y1, y2), "split-K result is not reproducible"
-    lib.dgvit_set_gemm_split(0)
-    try:
+    with knobs(gemm_split=0):       # the unsplit kernel: A/B knob of the diagnostic library
         y0 = run()
-    finally:
-        lib.dgvit_set_gemm_split(1)
     ref = A.double().cpu() @ (B.double().cpu().T if layout == 0 else B.double().cpu())
     if bias is not None:
         ref = ref + bias.double().cpu()
@@ -799,8 +796,9 @@ def test_standalone_rmsnorm_with_unit_offset(amd, unit_offset):
 
 
 # ------------------------------------------------------------------------------------------------ small-batch (per-frame) forward
-def _small_path(lib, on):
-    lib.dgvit_set_small_batch_path(1 if on else 0, 0)
+def _small_path(on):
+    """the per-frame experiment lives in the diagnostic library only (frame.hip is not part of the product)"""
+    return knobs(force_diag=True, small_batch_path=(1 if on else 0, 0))
 
 
 @pytest.mark.parametrize("name,cls", [("policy_native_shipped", "policy"), ("policy_native_small", "policy"), ("policy_c2", "policy"),
@@ -817,13 +815,8 @@ def test_small_batch_path_matches_reference_goldens(amd, name, cls):
     else:
         m = _load_state(amd.DeterministicGoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, **kw), O.make_params(O.detpolicy_param_spec(cfg), seed)).eval().to("cuda")
     img, pstate, _, _ = O.make_inputs(cfg, batch, seed)
-    lib = amd.load_library()
-    _small_path(lib, True)
-    try:
-        with torch.no_grad():
-            out = m([img.cuda(), pstate.cuda()])
-    finally:
-        _small_path(lib, False)
+    with _small_path(True), torch.no_grad():
+        out = m([img.cuda(), pstate.cuda()])
     if cls == "policy":
         np.testing.assert_allclose(out[0].cpu().numpy(), fx["mean"], rtol=0, atol=OUT_TOL)
         np.testing.assert_allclose(out[1].cpu().numpy(), fx["log_std"], rtol=0, atol=OUT_TOL)
@@ -841,7 +834,6 @@ def test_small_batch_path_matches_reference_goldens(amd, name, cls):
 def test_small_batch_path_equals_large_batch_schedule(amd, image, patch, dim, depth, heads, dim_head, B):
     """Same module, same inputs, eval and train mode (same dropout seed): the per-frame kernels and the GEMM schedule must agree
     to fp32 summation-order rounding, and both with the oracle."""
-    lib = amd.load_library()
     cfg = O.GoTConfig(image=image, patch=patch, dim=dim, depth=depth, heads=heads, dim_head=dim_head, mlp_dim=256 if dim < 64 else 2048)
     params = O.make_params(O.got_param_spec(cfg, prefix=""), 17)
     m = amd.GoT(image_size=image, patch_size=patch, num_classes=2, dim=dim, depth=depth, heads=heads, mlp_dim=cfg.mlp_dim, channels=1, dim_head=dim_head)
@@ -854,13 +846,10 @@ def test_small_batch_path_equals_large_batch_schedule(amd, image, patch, dim, de
     for mode in ("eval", "train"):
         m.train(mode == "train")
         for on in (True, False):
-            _small_path(lib, on)
-            try:
+            with _small_path(on):
                 torch.manual_seed(5)      # same dropout seed draw for both paths
                 with torch.no_grad():
                     outs[(mode, on)] = m(img.cuda(), goal.cuda()).cpu()
-            finally:
-                _small_path(lib, False)      # the library's default
         np.testing.assert_allclose(outs[(mode, True)].numpy(), outs[(mode, False)].numpy(), rtol=0, atol=5e-5)
     if ref is not None:
         np.testing.assert_allclose(outs[("eval", True)].numpy(), ref.detach().numpy(), rtol=0, atol=OUT_TOL)
@@ -906,16 +895,13 @@ def test_attention_backward_single_pass_equals_two_phase(B, N, H, dh):
     it replaces for these shapes are the same function: equal up to fp32 summation order."""
     import dgvit_amd
     from dgvit_amd import functional as F
-    lib = dgvit_amd.load_library()
+    dgvit_amd.load_library()
     g = torch.Generator().manual_seed(N * 7 + H)
     qkv = torch.randn(B, N, 3 * H * dh, generator=g).cuda()
     dout = torch.randn(B, N, H * dh, generator=g).cuda()
     out, lse = F.op_attention_fwd(qkv, H, dh)
-    try:
-        lib.dgvit_set_attention_bwd_single_pass(0)
+    with knobs(attention_bwd_single_pass=0):
         two_phase = F.op_attention_bwd(qkv, out, dout, lse, H, dh).clone()
-    finally:
-        lib.dgvit_set_attention_bwd_single_pass(1)
     single = F.op_attention_bwd(qkv, out, dout, lse, H, dh)
     assert torch.isfinite(single).all()
     torch.testing.assert_close(single, two_phase, atol=2e-5, rtol=1e-5)
@@ -942,7 +928,6 @@ def test_persistent_gemm_equals_per_tile_kernel(layout, epi, M, N, K, tile, wgs)
     ragged edges included."""
     import dgvit_amd
     from dgvit_amd import functional as F
-    lib = dgvit_amd.load_library()
     g = torch.Generator().manual_seed(M + N + K + epi)
     A = torch.randn(M, K, generator=g).cuda()
     B = (torch.randn(N, K, generator=g) if layout == 0 else torch.randn(K, N, generator=g)).cuda()
@@ -951,22 +936,16 @@ def test_persistent_gemm_equals_per_tile_kernel(layout, epi, M, N, K, tile, wgs)
     aux = torch.randn(M, N, generator=g).cuda() if epi in (2, 4) else None
 
     def run(mode):
-        lib.dgvit_set_gemm_tile(tile)
-        lib.dgvit_set_gemm_persistent(mode, wgs)
-        lib.dgvit_set_gemm_split(0)          # (split tiles sum their k-slices in another order: not the comparison made here)
-        try:
+        # (split tiles sum their k-slices in another order: not the comparison made here)
+        with knobs(force_diag=True, gemm_tile=tile, gemm_persistent=(mode, wgs), gemm_split=0) as lib:
+            before = lib.dgvit_gemm_persistent_launches()
             out = F.op_gemm(layout, epi, A, B, M, N, K, bias=bias, res=res, aux=aux, want_c2=(epi == 1))
             torch.cuda.synchronize()
-        finally:
-            lib.dgvit_set_gemm_tile(0)
-            lib.dgvit_set_gemm_persistent(0, 0)
-            lib.dgvit_set_gemm_split(1)
+            assert lib.dgvit_gemm_persistent_launches() == before + (1 if mode else 0), "the launch did not take the pipelined kernel"
         return out if isinstance(out, tuple) else (out,)
 
     ref = run(0)
-    before = lib.dgvit_gemm_persistent_launches()
     got = run(2)
-    assert lib.dgvit_gemm_persistent_launches() == before + 1, "the launch did not take the pipelined kernel"
     for r, o in zip(ref, got):
         assert torch.isfinite(o).all()
         assert torch.equal(r, o), f"max diff {(r - o).abs().max().item()}"
@@ -978,9 +957,7 @@ def test_persistent_gemm_writes_nothing_outside_c():
     the matrix (rows past M and the columns between N and ldc)."""
     import dgvit_amd
     from dgvit_amd import _lib
-    lib = dgvit_amd.load_library()
     M, N, K, ldc = 203, 132, 256, 160
-    lib.dgvit_set_gemm_tile(64128016)
     g = torch.Generator().manual_seed(5)
     A = torch.randn(M, K, generator=g).cuda()
     B = torch.randn(N, K, generator=g).cuda()
@@ -988,18 +965,14 @@ def test_persistent_gemm_writes_nothing_outside_c():
     pad = 4096
     buf = torch.full((pad + M * ldc + pad,), 777.0, device="cuda")
     C = buf[pad:pad + M * ldc].view(M, ldc)
-    nsc = lib.dgvit_gemm_scratch_floats(0, M, N, K)
-    scratch = torch.zeros(max(nsc, 4), device="cuda")
-    lib.dgvit_set_gemm_persistent(2, 3)
-    before = lib.dgvit_gemm_persistent_launches()
-    try:
+    with knobs(force_diag=True, gemm_tile=64128016, gemm_persistent=(2, 3)) as lib:
+        nsc = lib.dgvit_gemm_scratch_floats(0, M, N, K)
+        scratch = torch.zeros(max(nsc, 4), device="cuda")
+        before = lib.dgvit_gemm_persistent_launches()
         rc = lib.dgvit_gemm(0, 0, A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), ldc, M, N, K, bias.data_ptr(), None, 0, None, 0, None, 0,
                             scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream)
-    finally:
-        lib.dgvit_set_gemm_persistent(0, 0)
-        lib.dgvit_set_gemm_tile(0)
-    _lib.check(rc, "dgvit_gemm")
-    assert lib.dgvit_gemm_persistent_launches() == before + 1
+        _lib.check(rc, "dgvit_gemm")
+        assert lib.dgvit_gemm_persistent_launches() == before + 1
     torch.cuda.synchronize()
     ref = (A.double() @ B.double().t() + bias.double()).float()
     torch.testing.assert_close(C[:, :N], ref, atol=2e-4, rtol=1e-5)
@@ -1031,17 +1004,14 @@ def test_direct_gemm_epilogue_stays_inside_c(layout, epi, M, N, K, ldc):
         buf = torch.full((pad + M * ldc + pad,), 555.0, device="cuda")
         buf2 = torch.full((pad + M * ldc + pad,), 555.0, device="cuda")
         C, C2 = buf[pad:pad + M * ldc].view(M, ldc), buf2[pad:pad + M * ldc].view(M, ldc)
-        lib.dgvit_set_gemm_diagnostics(diag)
-        lib.dgvit_set_gemm_split(0)
-        try:
-            rc = lib.dgvit_gemm(layout, epi, A.data_ptr(), K, B.data_ptr(), K if layout == 0 else N, C.data_ptr(), ldc, M, N, K,
-                                bias.data_ptr() if bias is not None else None, res.data_ptr() if res is not None else None, N,
-                                C2.data_ptr() if epi == 1 else None, ldc, aux.data_ptr() if aux is not None else None, N,
-                                scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream)
-        finally:
-            lib.dgvit_set_gemm_diagnostics(0)
-            lib.dgvit_set_gemm_split(1)
-        _lib.check(rc, "dgvit_gemm")
+        # diag 0: the product library's direct epilogue (split off only matters for the equality with the LDS-image form below,
+        # these shapes do not split); diag 8: the LDS-image epilogue forced in the diagnostic library
+        with knobs(gemm_diagnostics=diag, gemm_split=1 if diag == 0 else 0) as klib:
+            rc = klib.dgvit_gemm(layout, epi, A.data_ptr(), K, B.data_ptr(), K if layout == 0 else N, C.data_ptr(), ldc, M, N, K,
+                                 bias.data_ptr() if bias is not None else None, res.data_ptr() if res is not None else None, N,
+                                 C2.data_ptr() if epi == 1 else None, ldc, aux.data_ptr() if aux is not None else None, N,
+                                 scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "dgvit_gemm")
         torch.cuda.synchronize()
         for b_, c_ in ((buf, C),) + (((buf2, C2),) if epi == 1 else ()):
             assert (c_[:, N:] == 555.0).all(), "columns between N and ldc were written"
@@ -1077,9 +1047,7 @@ def test_layernorm_fused_into_gemm_epilogue_is_bit_identical(B, split):
     ps = torch.rand(B, 2, generator=g).cuda()
 
     def run(fused, train):
-        lib.dgvit_set_ln_fusion(fused)
-        lib.dgvit_set_gemm_split(split)
-        try:
+        with knobs(ln_fusion=fused, gemm_split=split):     # (1, 1) = the product library itself
             model.train(train)
             torch.manual_seed(5)           # same embedding-dropout mask in both schedules
             for p_ in model.parameters():
@@ -1090,9 +1058,6 @@ def test_layernorm_fused_into_gemm_epilogue_is_bit_identical(B, split):
             torch.cuda.synchronize()
             grads = [p_.grad.clone() for p_ in model.parameters() if p_.grad is not None]
             return mean.detach().clone(), log_std.detach().clone(), grads
-        finally:
-            lib.dgvit_set_ln_fusion(1)
-            lib.dgvit_set_gemm_split(1)
 
     for train in (False, True):
         a, b = run(1, train), run(0, train)
@@ -1119,16 +1084,13 @@ def test_conv_forward_gather_equals_im2col(B, H, W):
     act = (torch.rand(B, 2, generator=g) * 2 - 1).cuda()
 
     def run(on):
-        lib.dgvit_set_conv_gather(on)
-        try:
+        with knobs(conv_gather=on):
             for p_ in net.parameters():
                 p_.grad = None
             q1, q2 = net([img, ps, act])
             (q1.square().mean() + q2.mean()).backward()
             torch.cuda.synchronize()
             return q1.detach().clone(), q2.detach().clone(), [p_.grad.clone() for p_ in net.parameters() if p_.grad is not None]
-        finally:
-            lib.dgvit_set_conv_gather(1)
 
     a, b = run(1), run(0)
     assert torch.isfinite(a[0]).all()

@@ -6,11 +6,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import dgvit_amd, synthetic
 from dgvit_amd.optim import FlatAdam
-lib = dgvit_amd.load_library()
+lib = dgvit_amd.diagnostic_library().__enter__()   # libdgvit_hip_diag.so: the A/B knobs live there (include/dgvit_hip_diag.h)
 knob = sys.argv[1] if len(sys.argv) > 1 else "grouped_reduce"
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 on_value = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # value passed for the "1" arm (bit masks: gemm_diagnostics 8 = LDS-image epilogue)
-setter = getattr(lib, "dgvit_set_" + knob)
+if knob == "wgrad_overlap":      # a per-module schedule option now (dgvit_config.flags), not a library knob
+    setter = lambda v: model.trans.set_schedule(wgrad_overlap=bool(v))
+else:
+    setter = getattr(lib, "dgvit_set_" + knob)
 dev = torch.device("cuda")
 torch.manual_seed(3407)
 model = dgvit_amd.GoTPolicy(2, 2, 6, 8, 256, image_size=(84, 84), patch_size=(12, 12)).to(dev).train()

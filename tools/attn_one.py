@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import dgvit_amd
 from dgvit_amd import functional as F
-lib = dgvit_amd.load_library()
+lib = dgvit_amd.diagnostic_library().__enter__()   # libdgvit_hip_diag.so: the A/B knobs live there (include/dgvit_hip_diag.h)
 B, N, H, dh = int(os.environ.get("B", 512)), int(os.environ.get("N", 50)), 8, 64
 qkv = torch.randn(B, N, 3 * H * dh, device="cuda")
 dout = torch.randn(B, N, H * dh, device="cuda")

@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--no-forward", action="store_true")
     ap.add_argument("--mfma16", type=int, default=-1, help="force the ring GEMM's MFMA shape: 1 = 16x16x32, 0 = 32x32x16 (default: library default)")
     a = ap.parse_args()
-    lib = dgvit_amd.load_library()
+    lib = dgvit_amd.diagnostic_library().__enter__()   # libdgvit_hip_diag.so: the A/B knobs live there (include/dgvit_hip_diag.h)
     if a.mfma16 >= 0:
         lib.dgvit_set_gemm_bf16_mfma16(a.mfma16)
     B, N, D, I, M = a.batch, 197, 768, 768, 3072

@@ -10,7 +10,7 @@ from dgvit_amd import functional as F  # noqa: E402
 
 M, N, K, tile, epi = (int(v) for v in sys.argv[1:6])
 iters = int(sys.argv[6]) if len(sys.argv) > 6 else 5
-lib = dgvit_amd.load_library()
+lib = dgvit_amd.diagnostic_library().__enter__()   # libdgvit_hip_diag.so: the A/B knobs live there (include/dgvit_hip_diag.h)
 g = torch.Generator(device="cuda").manual_seed(0)
 x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
 w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)

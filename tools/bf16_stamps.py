@@ -17,7 +17,7 @@ from dgvit_amd import functional as F  # noqa: E402
 M, N, K = (int(v) for v in sys.argv[1:4])
 tile = int(sys.argv[4]) if len(sys.argv) > 4 else 256256
 bm, bn = tile // 1000, tile % 1000
-lib = dgvit_amd.load_library()
+lib = dgvit_amd.diagnostic_library().__enter__()   # libdgvit_hip_diag.so: the A/B knobs live there (include/dgvit_hip_diag.h)
 g = torch.Generator(device="cuda").manual_seed(0)
 x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
 w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)

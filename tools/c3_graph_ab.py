@@ -14,9 +14,9 @@ lib = dgvit_amd.load_library()
 B = 512
 out = {}
 for overlap in (0, 1):
-    lib.dgvit_set_wgrad_overlap(overlap)
     torch.manual_seed(3407)
     model = dgvit_amd.GoTPolicy(2, 2, 6, 8, 256, image_size=(84, 84), patch_size=(12, 12)).to(dev).train()
+    model.trans.set_schedule(wgrad_overlap=bool(overlap))
     opt = FlatAdam([model], lr=1e-4, capturable=True)
     img, pstate, _, _ = (t.to(dev) for t in synthetic.make_inputs((84, 84), B, 3407))
     tm, tl = torch.randn(B, 2, device=dev), torch.randn(B, 2, device=dev)
@@ -46,5 +46,4 @@ for overlap in (0, 1):
     out[f"overlap{overlap}"] = {"eager_ms": round(eager, 3), "graph_ms": round(graph, 3), "eager_fps": round(B / eager * 1e3),
                                 "graph_fps": round(B / graph * 1e3)}
     print(out, flush=True)
-lib.dgvit_set_wgrad_overlap(0)
 print(json.dumps(out))

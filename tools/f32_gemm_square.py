@@ -7,9 +7,9 @@ import torch
 import dgvit_amd
 from dgvit_amd import functional as F
 
-lib = dgvit_amd.load_library()
+lib = dgvit_amd.diagnostic_library().__enter__()   # libdgvit_hip_diag.so: the A/B knobs live there (include/dgvit_hip_diag.h)
 dev = "cuda"
-HINTS = [128128032, 128128016, 64064032, 128064016, 64128016]
+HINTS = [128128032, 128128016, 64064032, 64128016]
 for n in (4096, 8192):
     for zeros in (0, 1):
         A = torch.zeros(n, n, device=dev) if zeros else torch.randn(n, n, device=dev)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import dgvit_amd
 from dgvit_amd import functional as F
-lib = dgvit_amd.load_library()
+lib = dgvit_amd.diagnostic_library().__enter__()   # libdgvit_hip_diag.so: the A/B knobs live there (include/dgvit_hip_diag.h)
 dev = "cuda"
 CASES = [("qkv fwd NT 25600x1536x256 64x128x16", 0, 0, 25600, 1536, 256, 64128016, 30720),
          ("fc1 fwd NT 25600x2048x256 64x128x16 gelu2", 0, 1, 25600, 2048, 256, 64128016, 30720),
@@ -42,7 +42,7 @@ for name, layout, epi, m, n, k in [("qkv fwd", 0, 0, 25600, 1536, 256), ("fc1 fw
     bias = torch.randn(n, device=dev) if layout == 0 else None
     aux = torch.randn(m, n, device=dev) if epi == 2 else None
     row = []
-    for hint in (64128016, 128064016, 64064016, 64064032):
+    for hint in (64128016, 64064016, 64064032):
         lib.dgvit_set_gemm_tile(hint)
         ts = []
         for r in range(4):

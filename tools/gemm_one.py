@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import dgvit_amd
 from dgvit_amd import functional as F
-lib = dgvit_amd.load_library()
+lib = dgvit_amd.diagnostic_library().__enter__()   # libdgvit_hip_diag.so: the A/B knobs live there (include/dgvit_hip_diag.h)
 layout, epi, m, n, k, hint = (int(v) for v in sys.argv[1:7])
 reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
 dev = "cuda"

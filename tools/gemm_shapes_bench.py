@@ -7,7 +7,7 @@ import torch
 import dgvit_amd
 from dgvit_amd import functional as F
 
-lib = dgvit_amd.load_library()
+lib = dgvit_amd.diagnostic_library().__enter__()   # libdgvit_hip_diag.so: the A/B knobs live there (include/dgvit_hip_diag.h)
 T = int(os.environ.get("T", 25600))
 D, I, M = 256, 512, 2048
 dev = "cuda"
@@ -46,7 +46,7 @@ def run(layout, epi, m, n, k, hint):
     return times[len(times) // 2]
 
 
-HINTS = [128128032, 128128016, 64064032, 64064064, 128064032, 64128032, 128064016, 64128016]
+HINTS = [128128032, 128128016, 64064032, 64064064, 128064032, 64128032, 64128016]
 tot = {}
 best_sum = 0.0
 for name, layout, epi, m, n, k in SHAPES:

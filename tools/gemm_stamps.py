@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import dgvit_amd
 from dgvit_amd import functional as F
-lib = dgvit_amd.load_library()
+lib = dgvit_amd.diagnostic_library().__enter__()   # libdgvit_hip_diag.so: the A/B knobs live there (include/dgvit_hip_diag.h)
 dev = "cuda"
 
 CASES = [("qkv fwd  NT N=1536 K=256 ", 0, 0, 1536, 256, 64, 128, 16),

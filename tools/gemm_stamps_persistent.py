@@ -6,7 +6,7 @@ import numpy as np
 import torch
 import dgvit_amd
 from dgvit_amd import functional as F
-lib = dgvit_amd.load_library()
+lib = dgvit_amd.diagnostic_library().__enter__()   # libdgvit_hip_diag.so: the A/B knobs live there (include/dgvit_hip_diag.h)
 dev = "cuda"
 M = 25600
 for name, layout, epi, n, k, hint in [("qkv fwd NT N=1536 K=256", 0, 0, 1536, 256, 64128016), ("fc1 fwd NT N=2048 K=256 gelu2", 0, 1, 2048, 256, 64128016),
