@@ -37,6 +37,9 @@ struct GemmBf16Params {
 };
 
 int gemm_bf16(int epi, const GemmBf16Params& p, hipStream_t st);
+// gemm_bf16_stream.hip: the 64-deep / 128-byte-line kernel for the plain NT forms (bias, GELU, fp32 out); gemm_bf16 dispatches to it
+bool gemm_bf16_stream_supports(int epi, const GemmBf16Params& p);
+int gemm_bf16_stream(int epi, const GemmBf16Params& p, hipStream_t st);
 
 int cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t st);
 int patchify_bf16(const float* img, bf16_t* patches, int B, int ih, int iw, int ph, int pw, hipStream_t st);

@@ -1,0 +1,373 @@
+// bf16 GEMM for gfx950, "stream" kernel:  C[m][n] = sum_k A[m][k] * B[n][k]  (+ bias, erf-GELU), A / B bf16 with k contiguous,
+// fp32 accumulate on v_mfma_f32_16x16x32_bf16.  The Linear layers of Attention and FeedForward (GoalFormer.py:42-50,64,66-69) in
+// the bf16 configuration (BASELINE config 5), forward and data-gradient forms.
+//
+// What is different from gemm_bf16_ring_kernel (gemm_bf16.hip), and why (measured, tools/native/dma_probe.hip):
+//  * FULL 128-BYTE LINES PER LDS-DMA INSTRUCTION.  A `buffer_load_dwordx4 ... lds` whose 64 lanes cover 16 rows x 64 bytes (a 32-deep
+//    k-tile) tops out at 53-57 GB/s per CU whatever the tile, the ring depth or the cache state -- 1.75 PFLOP/s for a 256 x 256 tile
+//    and the ring kernel already runs at 70 % of that.  8 rows x 128 bytes (a 64-deep k-tile) delivers 85-90 GB/s per CU.
+//    A k-tile is therefore 64 deep: two PIECES of 256 rows x 128 bytes (32 KB), one of A and one of B, in a ring of five
+//    (all 160 KB of LDS: the epilogue needs none).  Rows are swizzled by 16-byte chunk c -> c ^ ((row >> 1) & 7) on the SOURCE
+//    address and again by the fragment reads (conflict-free for the 16x16x32 operand pattern of ds_read_b128).
+//  * NO PING-PONG.  With 64 KB per k-tile the LDS holds 2.5 k-tiles; a ping-pong pair keeps a k-tile "being read" for two and a half
+//    load / compute intervals and leaves a piece ~1 interval to arrive.  Here all eight waves run the same software pipeline: the
+//    fragments of the NEXT 32-deep half are read into a second register set while the MFMAs of the current half run, so a k-tile
+//    is read for exactly one k-tile period, ONE barrier per 64-deep k-tile hands its slots to the DMA stream, and a piece has
+//    1 (B, the L2-resident weights) to 2.5 (A) periods of ~2 k cycles to land.
+//  * THE DMA ISSUE IS SPREAD over the MFMAs (one instruction per eight MFMAs): issued as a burst of 4 x 8 waves the memory pipeline's
+//    queue backs up and the issuing waves stall in front of it.
+//  * DIRECT EPILOGUE.  The MFMA operands are swapped (weights as the A operand), so a lane's four accumulator registers of a
+//    16 x 16 block are four CONSECUTIVE output columns of one row: bias / GELU / bf16 conversion and one 8-byte (bf16) or
+//    16-byte (fp32) buffer store straight from registers.  No LDS staging, no wave barriers, no VMEM loads: the bias comes in by
+//    scalar loads (s_buffer_load, range-checked), because an ordinary load makes hipcc wait vmcnt(0) while LDS-DMAs are in
+//    flight (cdna_hip_programming.md, "Pipelining across barriers") -- a whole ring of DMA latency per tile.
+//  * Persistent as before: one workgroup per CU walks tiles id, id + grid, ...; the k-tile stream runs on across tile boundaries.
+// vmcnt bookkeeping (loads, LDS-DMAs and stores retire in order on one counter): piece j is issued in the half-phase that
+// precedes... see the loop; every wait is `vmcnt(4)` (the piece issued during the current phase may stay in flight), so the
+// stores of an epilogue simply have to be older than the next barrier's wait, which they are by a whole k-tile period.
+#include "bf16.h"
+#include "kernels.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+constexpr unsigned OOB = 0x80000000u;
+constexpr int PIECE = 256 * 128;   // bytes of one piece: 256 rows x 64 k
+constexpr int NSLOT = 5;
+
+__device__ __forceinline__ int xcd_chunk(int id, int n) {
+  // blocks are dealt round-robin over the 8 XCDs: give each XCD one contiguous chunk of the tile grid (bijective)
+  const int q = n >> 3, r = n & 7, xcd = id & 7, loc = id >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Issue order of one half (one basic block: 12 fragment reads of the NEXT half, 32 MFMAs, 4 LDS-DMAs): the four B fragments first,
+// then per A row block its 4 MFMAs followed by the read of the block's next fragment, and one DMA after every second block, so that
+// the 32 DMA instructions a CU issues per half arrive at the memory pipeline evenly (~1 per 32 cycles; it takes ~1 per 24): issued
+// as a burst at the top of the half they back up its queue and the waves stall in front of it before their first MFMA.
+// (LLVM SchedGroupMask: MFMA 0x8, VMEM 0x10, DS read 0x100.)
+__device__ __forceinline__ void sched_half() {
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    if (i & 1) __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+  }
+}
+
+// Timing diagnostics (diagnostic build only, dgvit_set_gemm_diagnostics; results are garbage): bit 0 (1) every piece re-fetches k-tile 0
+// of its tile (cache-hot source), bit 1 (2) no LDS-DMA at all, bit 2 (4) no fragment reads inside the loop, bit 3 (8) no epilogue,
+// bit 4 (16) no barrier, bit 5 (32) no MFMAs.
+// (compile-time variants: a run-time test around every MFMA wrecks the very schedule being measured)
+#define SDIAG(b) ((DIAG & (b)) != 0)
+
+template <int EPI, int DIAG = 0>
+__global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Params p, int ntiles) {
+  constexpr bool OUT_F32 = EPI == BEPI_F32_PLAIN;
+  constexpr int ES = OUT_F32 ? 4 : 2;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;          // wave tile: rows 128 wr .. + 127, columns 64 wc .. + 63
+  const int l15 = lane & 15, q = lane >> 4;
+  const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
+  // tile order inside an XCD's chunk: groups of group_m row panels walked column by column (their A and B k-slices share the L2)
+  auto tile_mn = [&](int t, int& m0, int& n0) {
+    const int GROUP_M = p.group_m;
+    const int per_group = GROUP_M * tiles_n, grp_i = t / per_group, within = t - grp_i * per_group;
+    const int rows = tiles_m - grp_i * GROUP_M < GROUP_M ? tiles_m - grp_i * GROUP_M : GROUP_M;
+    m0 = (grp_i * GROUP_M + within % rows) * 256;
+    n0 = (within / rows) * 256;
+  };
+  const int nkt = (p.K + 63) / 64;                  // 64-deep k-tiles per output tile
+
+  // ---- load side: the stream of pieces A(0) B(0) A(1) B(1) ... of all this workgroup's tiles, piece j -> slot j % 5 -------------
+  // instruction i (0..3) of a wave fills rows 64 i + 8 wave + (lane >> 3) of the piece; the lane's physical 16-byte chunk lane & 7
+  // holds logical chunk (lane & 7) ^ ((row >> 1) & 7), and (row >> 1) & 7 = (4 (wave & 1) + (lane >> 4)) & 7 for every i
+  const int lrow = 8 * wave + (lane >> 3);
+  const int lchunk = (lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7);
+  const unsigned offA = ((unsigned)lrow * (unsigned)p.lda + lchunk * 8u) * 2u, stepA = 64u * (unsigned)p.lda * 2u;
+  const unsigned offB = ((unsigned)lrow * (unsigned)p.ldb + lchunk * 8u) * 2u, stepB = 64u * (unsigned)p.ldb * 2u;
+  int ltile = blockIdx.x, lt = 0, lslot = 0, lop = 0;
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  auto set_load_tile = [&](int v) {
+    int m0, n0;
+    tile_mn(xcd_chunk(v, ntiles), m0, n0);
+    long long abytes = ((long long)(p.M - 1 - m0) * p.lda + p.K) * 2, bbytes = ((long long)(p.N - 1 - n0) * p.ldb + p.K) * 2;
+    if (abytes > 0x7FFFFFF0ll) abytes = 0x7FFFFFF0ll;
+    if (bbytes > 0x7FFFFFF0ll) bbytes = 0x7FFFFFF0ll;
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A + (long long)m0 * p.lda), 0, (int)abytes, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B + (long long)n0 * p.ldb), 0, (int)bbytes, 0x00020000);
+  };
+  set_load_tile(ltile);   // blockIdx.x < ntiles by construction of the grid
+  // Instruction i (0..3) of the A / B piece of the load side's current k-tile; an A piece is issued during the first half of a k-tile's
+  // MFMAs, a B piece during the second (the pieces alternate A, B like the halves), then the state advances.  Straight-line code, so
+  // that a whole half (fragment reads, 32 MFMAs, 4 DMAs) is ONE basic block whose issue order sched_group_barrier can pin.
+  // Past the last tile the same instructions still issue (every lane out of range: zeros into a free slot): the vmcnt bookkeeping
+  // never changes.
+  unsigned ldead = lchunk * 8 < p.K ? 0u : OOB;
+  auto dma_a = [&](int i) {
+    if constexpr (!SDIAG(2))
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(smem + lslot * PIECE + wave * 1024 + i * 8192), 16,
+                                               ((offA + (SDIAG(1) ? 0u : (unsigned)lt * 128u)) | ldead) + i * stepA, 0, 0, 0);
+  };
+  auto dma_b = [&](int i) {
+    if constexpr (!SDIAG(2))
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(smem + lslot * PIECE + wave * 1024 + i * 8192), 16,
+                                               ((offB + (SDIAG(1) ? 0u : (unsigned)lt * 128u)) | ldead) + i * stepB, 0, 0, 0);
+  };
+  auto next_slot = [&]() { lslot = lslot + 1 == NSLOT ? 0 : lslot + 1; };
+  auto next_ktile = [&]() {     // after the B piece
+    if (++lt == nkt) {
+      lt = 0;
+      ltile += gridDim.x;
+      if (ltile < ntiles) set_load_tile(ltile);
+    }
+    ldead = (ltile < ntiles && lt * 64 + lchunk * 8 < p.K) ? 0u : OOB;
+  };
+
+  // ---- compute side ------------------------------------------------------------------------------------------------------
+  // fragment of 16 rows x 32 k: lane (l15, q) reads row l15, logical chunk q + 4 h of the 128-byte row (h = which 32-deep half):
+  // byte  row * 128 + ((q + 4 h) ^ ((row >> 1) & 7)) * 16  =  lane_off ^ (h << 6)  (+ 2048 per 16-row block)
+  const unsigned lane_off = (unsigned)l15 * 128u + (unsigned)((q ^ (l15 >> 1)) << 4);
+  const unsigned a_off = (unsigned)wr * 16384u + lane_off, b_off = (unsigned)wc * 8192u + lane_off;
+  f32x4 acc[8][4];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = zero4;   // (and again in the epilogue, block by block as they are staged)
+  bf16x8 fa0[8], fb0[4], fa1[8], fb1[4];
+  int ctile = blockIdx.x, ct = 0, cslot = 0;
+
+  // prologue: two k-tiles in flight, the first one landed, its first half in registers
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_a(i);
+    next_slot();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_b(i);
+    next_slot();
+    next_ktile();
+  }
+  wait_vmcnt<8>();
+  __builtin_amdgcn_s_barrier();
+  {
+    const unsigned char* sA = smem + a_off, *sB = smem + PIECE + b_off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb0[j] = *reinterpret_cast<const bf16x8*>(sB + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(sA + i * 2048);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  while (ctile < ntiles) {
+    const int s1 = cslot + 1 >= NSLOT ? cslot + 1 - NSLOT : cslot + 1, s2 = cslot + 2 >= NSLOT ? cslot + 2 - NSLOT : cslot + 2,
+              s3 = cslot + 3 >= NSLOT ? cslot + 3 - NSLOT : cslot + 3;
+    // ---- first half of k-tile t: MFMAs on (fa0, fb0); fragments of its second half -> (fa1, fb1); piece 2 t + 4 is issued -------
+    {
+      const unsigned char* sA = smem + cslot * PIECE + (a_off ^ 64u), *sB = smem + s1 * PIECE + (b_off ^ 64u);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if constexpr (!SDIAG(4)) fb1[j] = *reinterpret_cast<const bf16x8*>(sB + j * 2048);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if constexpr (!SDIAG(32)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
+        if constexpr (!SDIAG(4)) fa1[i] = *reinterpret_cast<const bf16x8*>(sA + i * 2048);
+        if (i & 1) dma_a(i >> 1);
+      }
+      sched_half();
+    }
+    next_slot();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave holds every fragment of k-tile t ...
+    wait_vmcnt<4>();                                     // ... and its shares of pieces 2 t + 2, 2 t + 3 (k-tile t + 1) have landed
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!SDIAG(16)) __builtin_amdgcn_s_barrier();        // k-tile t + 1 is complete; the slots of k-tile t are free
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- second half: MFMAs on (fa1, fb1); first-half fragments of k-tile t + 1 -> (fa0, fb0); piece 2 t + 5 into a slot of k-tile t
+    if (EPI != BEPI_F32_PLAIN && ct == nkt - 1) {
+      // last k-tile of an output tile: the wave's 64 bias values go by ONE LDS-DMA (4 bytes per lane, range-checked: columns past N
+      // read 0) into the first 256 bytes of its staging area -- slot s1 is free from this barrier on.  (Scalar loads cost ~3 us
+      // each under this load, ordinary loads make hipcc wait vmcnt(0) behind the whole DMA ring.)  It is older than the four piece
+      // DMAs of this phase, so `vmcnt(4)` at the start of the epilogue covers it.
+      int bm0, bn0;
+      tile_mn(xcd_chunk(ctile, ntiles), bm0, bn0);
+      const bool has_bias = p.bias != nullptr;
+      const __amdgpu_buffer_rsrc_t rsb =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_bias ? p.bias : reinterpret_cast<const float*>(p.C)), 0, has_bias ? p.N * 4 : 0, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_ptr_t)(smem + s1 * PIECE + wave * 1024), 4, (unsigned)(bn0 + wc * 64 + lane) * 4u, 0, 0, 0);
+    }
+    {
+      const unsigned char* nA = smem + s2 * PIECE + a_off, *nB = smem + s3 * PIECE + b_off;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if constexpr (!SDIAG(4)) fb0[j] = *reinterpret_cast<const bf16x8*>(nB + j * 2048);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if constexpr (!SDIAG(32)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
+        if constexpr (!SDIAG(4)) fa0[i] = *reinterpret_cast<const bf16x8*>(nA + i * 2048);
+        if (i & 1) dma_b(i >> 1);
+      }
+      sched_half();
+    }
+    next_slot();
+    next_ktile();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    cslot = s2;
+    int cnkt = nkt;
+    if (++ct < cnkt) continue;
+
+    if constexpr (!SDIAG(8)) {
+    // ---- epilogue of tile `ctile`, straight from the accumulators: lane (l15, q) holds, for 16 x 16 block (i, j), row
+    // 128 wr + 16 i + l15 and the four consecutive columns 64 wc + 16 j + 4 q + (0..3) ------------------------------------------------
+    {
+      int m0, n0;
+      tile_mn(xcd_chunk(ctile, ntiles), m0, n0);
+      // C window of this tile: num_records ends with the tile's last valid row, so rows past M are dropped by the range check of the
+      // buffer stores; columns past N get an out-of-range column offset (N % 4 == 0: a lane's four columns are valid together)
+      const int vrows = p.M - m0 < 256 ? p.M - m0 : 256, vcols = p.N - n0 < 256 ? p.N - n0 : 256;
+      const int cbytes = ((vrows - 1) * p.ldc + vcols) * ES;
+      const __amdgpu_buffer_rsrc_t rsC =
+          __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.C) + ((long long)m0 * p.ldc + n0) * ES, 0, cbytes, 0x00020000);
+      __amdgpu_buffer_rsrc_t rsC2 = rsC;
+      if (EPI == BEPI_GELU2_BF16)
+        rsC2 = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.C2) + ((long long)m0 * p.ldc2 + n0) * 2, 0, cbytes, 0x00020000);
+      // Staging: partial-line stores straight from the accumulator layout (8 bytes per lane, 32-byte runs) drained at 2 TB/s and
+      // held up the DMA stream behind them (2.9 TB/s with 16-byte fp32 pieces).  The slot of piece B(t) is free between this
+      // k-tile's barrier and the next phase's DMA issue, and a wave's own four 1 KB DMA chunks of it are written by nobody else:
+      // they hold one 16-row x 64-column fp32 block (row r in chunk r >> 2, 16-byte pieces swizzled by ^ r), written as four
+      // ds_write_b128 from the accumulator layout and read back as 16 lanes x 16 bytes per row, so that every global store
+      // instruction covers four whole 128-byte (bf16) / 256-byte (fp32) rows.
+      unsigned char* stg = smem + s1 * PIECE + wave * 1024;
+      const unsigned w_off = (unsigned)(l15 >> 2) * 8192u + (unsigned)(l15 & 3) * 256u;      // + ((4 j + q) ^ l15) * 16
+      const int rr = lane >> 4, rc = lane & 15;                                               // read-back: row 4 u + rr, piece rc
+      const unsigned rowpart = (unsigned)(wr * 128 + rr) * (unsigned)p.ldc * ES, rowstep = 4u * (unsigned)p.ldc * ES;
+      const unsigned coloff = n0 + wc * 64 + 4 * rc < p.N ? (unsigned)(wc * 64 + 4 * rc) * ES : OOB;
+      fx4 bv[4];
+      if constexpr (EPI != BEPI_F32_PLAIN) {
+        wait_vmcnt<4>();      // the bias DMA (issued before this phase's four piece DMAs) has landed; same wave: no barrier needed
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const fx4*>(stg + (16 * j + 4 * q) * 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = fx4{0.f, 0.f, 0.f, 0.f};
+      }
+      unsigned off = rowpart + coloff;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+          *reinterpret_cast<fx4*>(stg + w_off + (unsigned)(((4 * j + q) ^ l15) << 4)) = acc[i][j] + bv[j];
+          acc[i][j] = zero4;      // the next tile accumulates from zero (a branch on "first k-tile" would split the half's basic block)
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (wave-private region: the wave's own writes are all it waits for)
+        __builtin_amdgcn_wave_barrier();
+        fx4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const fx4*>(stg + u * 8192 + rr * 256 + ((rc ^ (4 * u + rr)) << 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 4; ++u, off += rowstep) {
+          if constexpr (EPI == BEPI_F32_PLAIN) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v[u]), rsC, off, 0, 0);
+          } else {
+            if constexpr (EPI == BEPI_GELU2_BF16)   // ldc2 == ldc (checked at launch): the pre-activation copy shares the offset
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(v[u], bf16x4)), rsC2, off, 0, 0);
+            fx4 g = v[u];
+            if constexpr (EPI == BEPI_GELU_BF16 || EPI == BEPI_GELU2_BF16) g = fx4{gelu_erf(g[0]), gelu_erf(g[1]), gelu_erf(g[2]), gelu_erf(g[3])};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(g, bf16x4)), rsC, off, 0, 0);
+          }
+        }
+      }
+    }
+    }   // (SDIAG(8): epilogue skipped)
+    ct = 0;
+    ctile += gridDim.x;
+  }
+  wait_vmcnt<0>();   // the trailing (all-zero) LDS-DMAs must land before the workgroup gives its LDS back
+}
+
+int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+template <int EPI, int DIAG = 0>
+int launch_stream(const GemmBf16Params& p_in, hipStream_t st) {
+  GemmBf16Params p = p_in;
+  if (p.group_m <= 0) p.group_m = g_gemm_bf16_group_m > 0 ? g_gemm_bf16_group_m : 8;
+  const long long tiles = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  DGVIT_CHECK_ARG(tiles < (1ll << 30), "gemm_bf16: too many tiles");
+  DGVIT_CHECK_ARG((long long)258 * p.ldc * 4 < (1ll << 31) && (long long)258 * p.ldc2 * 2 < (1ll << 31), "gemm_bf16: output leading dimension too large");
+  DGVIT_CHECK_ARG(EPI != BEPI_GELU2_BF16 || p.ldc2 == p.ldc, "gemm_bf16: the GELU epilogue with a pre-activation copy needs ldc2 == ldc");
+  constexpr int LDS = NSLOT * PIECE;
+  auto kern = gemm_bf16_stream_kernel<EPI, DIAG>;
+  static DeviceOnce once;
+  if (const unsigned long long bit = once.pending()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+      return dgvit_set_error(DGVIT_ERR_HIP, "gemm_bf16: cannot raise the dynamic LDS limit to %d bytes", LDS);
+    once.mark(bit);
+  }
+  const int grid = (int)(tiles < num_cus() ? tiles : num_cus());   // one persistent workgroup per CU
+  const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, st);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS, st, p, (int)tiles);
+  profile_end(slot, st);
+  DGVIT_CHECK_LAUNCH("gemm_bf16_stream_kernel");
+  return DGVIT_OK;
+}
+
+}  // namespace
+
+// shapes / epilogues the stream kernel takes (the callers fall back to the ring / simple kernels otherwise)
+bool gemm_bf16_stream_supports(int epi, const GemmBf16Params& p) {
+  if (p.tn || p.ksplit > 1 || p.c_rgrp > 0 || p.res_mod > 0 || p.res) return false;
+  if (!(epi == BEPI_BF16 || epi == BEPI_GELU_BF16 || epi == BEPI_GELU2_BF16 || epi == BEPI_F32_PLAIN)) return false;
+  return p.K % 8 == 0 && p.N % 4 == 0;
+}
+
+int gemm_bf16_stream(int epi, const GemmBf16Params& p, hipStream_t st) {
+#ifdef DGVIT_DIAG   // timing variants (dgvit_set_gemm_diagnostics), epilogue 0 / 1 only
+  if (g_gemm_diag && epi == BEPI_F32_PLAIN) {
+    if (g_gemm_diag == 32) return launch_stream<BEPI_F32_PLAIN, 32>(p, st);
+    if (g_gemm_diag == 40) return launch_stream<BEPI_F32_PLAIN, 40>(p, st);
+    if (g_gemm_diag == 2) return launch_stream<BEPI_F32_PLAIN, 2>(p, st);
+  }
+  if (g_gemm_diag && (epi == BEPI_BF16 || epi == BEPI_GELU_BF16)) {
+#define DGVIT_SD(D)                                                                        \
+  if (g_gemm_diag == D) return epi == BEPI_BF16 ? launch_stream<BEPI_BF16, D>(p, st) : launch_stream<BEPI_GELU_BF16, D>(p, st);
+    DGVIT_SD(1) DGVIT_SD(2) DGVIT_SD(4) DGVIT_SD(8) DGVIT_SD(10) DGVIT_SD(14) DGVIT_SD(18) DGVIT_SD(30) DGVIT_SD(32) DGVIT_SD(40) DGVIT_SD(44) DGVIT_SD(16)
+#undef DGVIT_SD
+    return dgvit_set_error(DGVIT_ERR_ARG, "gemm_bf16_stream: no timing variant %d", g_gemm_diag);
+  }
+#endif
+  switch (epi) {
+    case BEPI_BF16: return launch_stream<BEPI_BF16>(p, st);
+    case BEPI_GELU_BF16: return launch_stream<BEPI_GELU_BF16>(p, st);
+    case BEPI_GELU2_BF16: return launch_stream<BEPI_GELU2_BF16>(p, st);
+    case BEPI_F32_PLAIN: return launch_stream<BEPI_F32_PLAIN>(p, st);
+    default: return dgvit_set_error(DGVIT_ERR_ARG, "gemm_bf16_stream: unsupported epilogue %d", epi);
+  }
+}

@@ -33,7 +33,7 @@ def timeit(fn, iters=20, warm=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--tiles", default="256256,256128,128128")
+    ap.add_argument("--tiles", default="256256,256257")
     ap.add_argument("--no-forward", action="store_true")
     ap.add_argument("--mfma16", type=int, default=-1, help="force the ring GEMM's MFMA shape: 1 = 16x16x32, 0 = 32x32x16 (default: library default)")
     a = ap.parse_args()

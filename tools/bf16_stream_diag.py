@@ -1,0 +1,47 @@
+"""Timing decomposition of the bf16 stream GEMM (diagnostic library): which of DMA delivery / fragment reads / barrier / MFMA / epilogue
+sets the pace.  python tools/bf16_stream_diag.py [batch]  -- results of the diagnostic arms are garbage by construction."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dgvit_amd  # noqa: E402
+from dgvit_amd import functional as F  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 440
+lib = dgvit_amd.diagnostic_library().__enter__()
+T = B * 197
+g = torch.Generator(device="cuda").manual_seed(0)
+ARMS = [("ring (old)", 256256, 0), ("stream", 256257, 0), ("hot source", 256257, 1), ("no dma", 256257, 2), ("no frag reads", 256257, 4),
+        ("no epilogue", 256257, 8), ("no dma, no epilogue", 256257, 10), ("no dma/reads/epi", 256257, 14), ("no barrier (dma off)", 256257, 18),
+        ("mfma only", 256257, 2 + 4 + 8 + 16), ("no mfma", 256257, 32), ("no mfma, no epilogue", 256257, 40), ("dma only", 256257, 32 + 4 + 8),
+        ("stream again", 256257, 0), ("ring again", 256256, 0)]
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(iters):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / iters
+
+
+for name, (m, n, k, epi) in {"qkv": (T, 2304, 768, 0), "qkv-f32out": (T, 2304, 768, 4), "fc1": (T, 3072, 768, 1), "fc2": (T, 768, 3072, 0)}.items():
+    x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(n, device="cuda", generator=g)
+    for arm, tile, diag in ARMS:
+        if epi == 4 and diag not in (0, 2, 32, 40):
+            continue
+        lib.dgvit_set_gemm_bf16_tile(tile)
+        lib.dgvit_set_gemm_diagnostics(diag)
+        ms = timeit(lambda: F.op_gemm_bf16(epi, x, w, bias=bias))
+        print(f"{name} ({m}, {n}, {k}) {arm:24s} {ms * 1e3:8.1f} us  {2.0 * m * n * k / ms / 1e9:8.1f} TFLOP/s-equivalent", flush=True)
+    lib.dgvit_set_gemm_diagnostics(0)
+    lib.dgvit_set_gemm_bf16_tile(0)
