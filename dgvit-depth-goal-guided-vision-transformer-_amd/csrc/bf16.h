@@ -33,6 +33,7 @@ struct GemmBf16Params {
   int ksplit, kchunk;           // ksplit > 1: K is cut into ksplit slices of kchunk (multiple of 32); slice z writes C + z * slab_stride
   long long slab_stride;        //             (BEPI_F32_PLAIN only; the slabs are summed by reduce_slabs)
   int group_m;                  // row panels per walk group (0 = default); see tile_mn in gemm_bf16_ring_kernel
+  int stagger; long long stagger_cycles;   // stream kernel: start phases of the workgroups and cycles between them (set at launch)
   int tn;                       // 1: A is (K, M) with row stride lda, B is (K, N): C = A^T B (BEPI_F32_PLAIN, 256 x 256 tile)
 };
 

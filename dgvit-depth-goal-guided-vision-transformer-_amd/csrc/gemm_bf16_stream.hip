@@ -45,6 +45,11 @@ __device__ __forceinline__ int xcd_chunk(int id, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// s_waitcnt lgkmcnt(0) as the BUILTIN (simm16: vmcnt 63, expcnt 7, lgkmcnt 0): hipcc's own wait insertion sees it, so it does not put
+// conservative `lgkmcnt(8)` waits in front of the next half's MFMAs for fragments this wait has already covered (an inline-asm wait is
+// invisible to its scoreboard; with the LDS busy taking DMA data those spurious waits stalled the MFMA stream).
+__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
@@ -56,19 +61,27 @@ __device__ __forceinline__ void wait_vmcnt() {
 // the 32 DMA instructions a CU issues per half arrive at the memory pipeline evenly (~1 per 32 cycles; it takes ~1 per 24): issued
 // as a burst at the top of the half they back up its queue and the waves stall in front of it before their first MFMA.
 // (LLVM SchedGroupMask: MFMA 0x8, VMEM 0x10, DS read 0x100.)
+template <int VAR, int PAR>
 __device__ __forceinline__ void sched_half() {
   __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    if (i & 1) __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+    if (VAR == 1 && (i & 1) == PAR) {   // the DMA in the middle of the block's MFMAs, away from the fragment reads
+      __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x8, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    } else {
+      __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (VAR != 1 && (i & 1) == PAR) __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+    }
   }
 }
 
 // Timing diagnostics (diagnostic build only, dgvit_set_gemm_diagnostics; results are garbage): bit 0 (1) every piece re-fetches k-tile 0
 // of its tile (cache-hot source), bit 1 (2) no LDS-DMA at all, bit 2 (4) no fragment reads inside the loop, bit 3 (8) no epilogue,
-// bit 4 (16) no barrier, bit 5 (32) no MFMAs.
+// bit 4 (16) no barrier, bit 5 (32) no MFMAs, bit 6 (64, with 8) the accumulators stay alive without an epilogue.
 // (compile-time variants: a run-time test around every MFMA wrecks the very schedule being measured)
 #define SDIAG(b) ((DIAG & (b)) != 0)
 
@@ -79,6 +92,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                        // waves w and w + 4 share a SIMD
   const int wr = wave >> 2, wc = wave & 3;          // wave tile: rows 128 wr .. + 127, columns 64 wc .. + 63
   const int l15 = lane & 15, q = lane >> 4;
   const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
@@ -150,7 +164,18 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
     for (int j = 0; j < 4; ++j) acc[i][j] = zero4;   // (and again in the epilogue, block by block as they are staged)
   bf16x8 fa0[8], fb0[4], fa1[8], fb1[4];
   int ctile = blockIdx.x, ct = 0, cslot = 0;
+  bool after_epi = false;
+  constexpr int NST = EPI == BEPI_GELU2_BF16 ? 64 : 32;   // global stores per wave and tile
 
+  // De-phasing: every workgroup would otherwise reach its tile boundaries at the same moment (equal tiles, one start), and the chip's
+  // whole output of a round -- 128 KB per CU, 32 MB in all -- would hit the L2s and HBM as one burst while the operand stream
+  // waits behind it.  Workgroups sharing an XCD (ids 8 apart) start `stagger` phases apart, a fraction of a tile period each.
+  if (p.stagger > 1) {
+    const int phase = ((int)blockIdx.x >> 3) % p.stagger;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    const long long wait = (long long)phase * p.stagger_cycles;
+    while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+  }
   // prologue: two k-tiles in flight, the first one landed, its first half in registers
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -171,7 +196,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
 #pragma unroll
     for (int i = 0; i < 8; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(sA + i * 2048);
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wait_lgkm0();
 
   while (ctile < ntiles) {
     const int s1 = cslot + 1 >= NSLOT ? cslot + 1 - NSLOT : cslot + 1, s2 = cslot + 2 >= NSLOT ? cslot + 2 - NSLOT : cslot + 2,
@@ -179,6 +204,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
     // ---- first half of k-tile t: MFMAs on (fa0, fb0); fragments of its second half -> (fa1, fb1); piece 2 t + 4 is issued -------
     {
       const unsigned char* sA = smem + cslot * PIECE + (a_off ^ 64u), *sB = smem + s1 * PIECE + (b_off ^ 64u);
+      auto first_half = [&](auto par) {
+      constexpr int PAR = decltype(par)::value;
 #pragma unroll
       for (int j = 0; j < 4; ++j) if constexpr (!SDIAG(4)) fb1[j] = *reinterpret_cast<const bf16x8*>(sB + j * 2048);
 #pragma unroll
@@ -186,31 +213,43 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
 #pragma unroll
         for (int j = 0; j < 4; ++j) if constexpr (!SDIAG(32)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
         if constexpr (!SDIAG(4)) fa1[i] = *reinterpret_cast<const bf16x8*>(sA + i * 2048);
-        if (i & 1) dma_a(i >> 1);
+        if ((i & 1) == PAR) dma_a(i >> 1);
       }
-      sched_half();
+      sched_half<(SDIAG(128) ? 1 : 0), PAR>();
+      };
+      if (SDIAG(256) && grp) first_half(std::integral_constant<int, 0>{});
+      else first_half(std::integral_constant<int, 1>{});
     }
     next_slot();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave holds every fragment of k-tile t ...
-    wait_vmcnt<4>();                                     // ... and its shares of pieces 2 t + 2, 2 t + 3 (k-tile t + 1) have landed
+    wait_lgkm0();   // this wave holds every fragment of k-tile t ...
+    // ... and its shares of pieces 2 t + 2, 2 t + 3 (k-tile t + 1) have landed: everything but the piece issued during this half.
+    // Right after an epilogue the tile's NST stores are younger than those pieces too and may stay in flight (every one of them is
+    // issued unconditionally, invalid rows / columns go out of range, so the count is exact): waiting for their acknowledgement
+    // here would stall the first k-tile of every tile behind the write stream.
+    if (after_epi) {
+      wait_vmcnt<(4 + NST <= 63 ? 4 + NST : 63)>();
+      after_epi = false;
+    } else {
+      wait_vmcnt<4>();
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!SDIAG(16)) __builtin_amdgcn_s_barrier();        // k-tile t + 1 is complete; the slots of k-tile t are free
     __builtin_amdgcn_sched_barrier(0);
     // ---- second half: MFMAs on (fa1, fb1); first-half fragments of k-tile t + 1 -> (fa0, fb0); piece 2 t + 5 into a slot of k-tile t
-    if (EPI != BEPI_F32_PLAIN && ct == nkt - 1) {
+    if (EPI != BEPI_F32_PLAIN && p.bias && ct == nkt - 1) {
       // last k-tile of an output tile: the wave's 64 bias values go by ONE LDS-DMA (4 bytes per lane, range-checked: columns past N
       // read 0) into the first 256 bytes of its staging area -- slot s1 is free from this barrier on.  (Scalar loads cost ~3 us
       // each under this load, ordinary loads make hipcc wait vmcnt(0) behind the whole DMA ring.)  It is older than the four piece
       // DMAs of this phase, so `vmcnt(4)` at the start of the epilogue covers it.
       int bm0, bn0;
       tile_mn(xcd_chunk(ctile, ntiles), bm0, bn0);
-      const bool has_bias = p.bias != nullptr;
-      const __amdgpu_buffer_rsrc_t rsb =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(has_bias ? p.bias : reinterpret_cast<const float*>(p.C)), 0, has_bias ? p.N * 4 : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, p.N * 4, 0x00020000);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (lds_ptr_t)(smem + s1 * PIECE + wave * 1024), 4, (unsigned)(bn0 + wc * 64 + lane) * 4u, 0, 0, 0);
     }
     {
       const unsigned char* nA = smem + s2 * PIECE + a_off, *nB = smem + s3 * PIECE + b_off;
+      auto second_half = [&](auto par) {
+      constexpr int PAR = decltype(par)::value;
 #pragma unroll
       for (int j = 0; j < 4; ++j) if constexpr (!SDIAG(4)) fb0[j] = *reinterpret_cast<const bf16x8*>(nB + j * 2048);
 #pragma unroll
@@ -218,13 +257,16 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
 #pragma unroll
         for (int j = 0; j < 4; ++j) if constexpr (!SDIAG(32)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
         if constexpr (!SDIAG(4)) fa0[i] = *reinterpret_cast<const bf16x8*>(nA + i * 2048);
-        if (i & 1) dma_b(i >> 1);
+        if ((i & 1) == PAR) dma_b(i >> 1);
       }
-      sched_half();
+      sched_half<(SDIAG(128) ? 1 : 0), PAR>();
+      };
+      if (SDIAG(256) && grp) second_half(std::integral_constant<int, 0>{});
+      else second_half(std::integral_constant<int, 1>{});
     }
     next_slot();
     next_ktile();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_lgkm0();
     __builtin_amdgcn_sched_barrier(0);
     cslot = s2;
     int cnkt = nkt;
@@ -252,54 +294,104 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
       // ds_write_b128 from the accumulator layout and read back as 16 lanes x 16 bytes per row, so that every global store
       // instruction covers four whole 128-byte (bf16) / 256-byte (fp32) rows.
       unsigned char* stg = smem + s1 * PIECE + wave * 1024;
-      const unsigned w_off = (unsigned)(l15 >> 2) * 8192u + (unsigned)(l15 & 3) * 256u;      // + ((4 j + q) ^ l15) * 16
       const int rr = lane >> 4, rc = lane & 15;                                               // read-back: row 4 u + rr, piece rc
       const unsigned rowpart = (unsigned)(wr * 128 + rr) * (unsigned)p.ldc * ES, rowstep = 4u * (unsigned)p.ldc * ES;
       const unsigned coloff = n0 + wc * 64 + 4 * rc < p.N ? (unsigned)(wc * 64 + 4 * rc) * ES : OOB;
       fx4 bv[4];
-      if constexpr (EPI != BEPI_F32_PLAIN) {
+      if (EPI != BEPI_F32_PLAIN && p.bias) {
         wait_vmcnt<4>();      // the bias DMA (issued before this phase's four piece DMAs) has landed; same wave: no barrier needed
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const fx4*>(stg + (16 * j + 4 * q) * 4);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_lgkm0();
         __builtin_amdgcn_wave_barrier();
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = fx4{0.f, 0.f, 0.f, 0.f};
       }
       unsigned off = rowpart + coloff;
+      if constexpr (OUT_F32) {
+        // fp32 output: one 16 x 64 fp32 block fills the wave's four chunks (row r in chunk r >> 2, 16-byte pieces swizzled by ^ r)
+        const unsigned w_off = (unsigned)(l15 >> 2) * 8192u + (unsigned)(l15 & 3) * 256u;      // + ((4 j + q) ^ l15) * 16
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 8; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-        {
-          *reinterpret_cast<fx4*>(stg + w_off + (unsigned)(((4 * j + q) ^ l15) << 4)) = acc[i][j] + bv[j];
-          acc[i][j] = zero4;      // the next tile accumulates from zero (a branch on "first k-tile" would split the half's basic block)
+          for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<fx4*>(stg + w_off + (unsigned)(((4 * j + q) ^ l15) << 4)) = acc[i][j];
+            acc[i][j] = zero4;      // the next tile accumulates from zero (a branch on "first k-tile" would split the half's basic block)
+          }
+          wait_lgkm0();     // (wave-private region: the wave's own writes are all it waits for)
+          __builtin_amdgcn_wave_barrier();
+          fx4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const fx4*>(stg + u * 8192 + rr * 256 + ((rc ^ (4 * u + rr)) << 4));
+          wait_lgkm0();
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int u = 0; u < 4; ++u, off += rowstep) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v[u]), rsC, off, 0, 0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (wave-private region: the wave's own writes are all it waits for)
-        __builtin_amdgcn_wave_barrier();
-        fx4 v[4];
+      } else {
+        // bf16 outputs are staged as finished bf16 values: a 16 x 64 block is 2 KB = two of the wave's chunks (row r in chunk r >> 3,
+        // 8-byte pieces swizzled by ^ ((r >> 1) & 7): conflict-free for the ds_write_b64 of the accumulator layout and the ds_read_b64
+        // of the row layout), so two blocks alternate and block i + 1 is written while block i's read is in flight: one LDS round
+        // trip per block on the critical path instead of two.  (GELU with a pre-activation copy stages both outputs, one pair of
+        // chunks each, without the overlap.)
+        constexpr bool TWO = EPI == BEPI_GELU2_BF16;
+        const unsigned w_off = (unsigned)(l15 >> 3) * 8192u + (unsigned)(l15 & 7) * 128u;       // + ((4 j + q) ^ ((l15 >> 1) & 7)) * 8
+        const unsigned wsw = (unsigned)((l15 >> 1) & 7);
+        auto stage = [&](int i, int buf) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const fx4*>(stg + u * 8192 + rr * 256 + ((rc ^ (4 * u + rr)) << 4));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+          for (int j = 0; j < 4; ++j) {
+            fx4 v = acc[i][j] + bv[j];
+            acc[i][j] = zero4;      // the next tile accumulates from zero
+            const unsigned a = w_off + (((unsigned)(4 * j + q) ^ wsw) << 3);
+            if constexpr (TWO) *reinterpret_cast<bf16x4*>(stg + 16384 + a) = __builtin_convertvector(v, bf16x4);   // pre-activation -> chunks 2, 3
+            if constexpr (EPI == BEPI_GELU_BF16 || EPI == BEPI_GELU2_BF16) v = fx4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+            *reinterpret_cast<bf16x4*>(stg + (TWO ? 0 : buf * 16384) + a) = __builtin_convertvector(v, bf16x4);
+          }
+        };
+        auto rd_off = [&](int u) {   // row 4 u + rr of the block, piece rc
+          const int row = 4 * u + rr;
+          return (unsigned)(row >> 3) * 8192u + (unsigned)(row & 7) * 128u + (((unsigned)rc ^ (unsigned)((row >> 1) & 7)) << 3);
+        };
+        stage(0, 0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u, off += rowstep) {
-          if constexpr (EPI == BEPI_F32_PLAIN) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v[u]), rsC, off, 0, 0);
-          } else {
-            if constexpr (EPI == BEPI_GELU2_BF16)   // ldc2 == ldc (checked at launch): the pre-activation copy shares the offset
-              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(v[u], bf16x4)), rsC2, off, 0, 0);
-            fx4 g = v[u];
-            if constexpr (EPI == BEPI_GELU_BF16 || EPI == BEPI_GELU2_BF16) g = fx4{gelu_erf(g[0]), gelu_erf(g[1]), gelu_erf(g[2]), gelu_erf(g[3])};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(g, bf16x4)), rsC, off, 0, 0);
+        for (int i = 0; i < 8; ++i) {
+          wait_lgkm0();     // block i is staged (wave-private region: its own writes are all it waits for)
+          __builtin_amdgcn_wave_barrier();
+          u32x2v v[4], v2[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            v[u] = *reinterpret_cast<const u32x2v*>(stg + (TWO ? 0 : (i & 1) * 16384) + rd_off(u));
+            if constexpr (TWO) v2[u] = *reinterpret_cast<const u32x2v*>(stg + 16384 + rd_off(u));
+          }
+          if constexpr (!TWO) {
+            if (i + 1 < 8) stage(i + 1, (i + 1) & 1);     // into the other pair of chunks, under this block's read latency
+          }
+          wait_lgkm0();
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int u = 0; u < 4; ++u, off += rowstep) {
+            if constexpr (TWO) __builtin_amdgcn_raw_buffer_store_b64(v2[u], rsC2, off, 0, 0);   // ldc2 == ldc (checked at launch): same offset
+            __builtin_amdgcn_raw_buffer_store_b64(v[u], rsC, off, 0, 0);
+          }
+          if constexpr (TWO) {
+            if (i + 1 < 8) stage(i + 1, 0);
           }
         }
       }
     }
+    } else if constexpr (SDIAG(64)) {   // timing: main loop with its MFMAs, nothing stored (the accumulators are kept alive, then cleared)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          asm volatile("" ::"v"(acc[i][j]));
+          acc[i][j] = zero4;
+        }
     }   // (SDIAG(8): epilogue skipped)
     ct = 0;
     ctile += gridDim.x;
+    after_epi = !SDIAG(8);
   }
   wait_vmcnt<0>();   // the trailing (all-zero) LDS-DMAs must land before the workgroup gives its LDS back
 }
@@ -318,8 +410,17 @@ int num_cus() {
 template <int EPI, int DIAG = 0>
 int launch_stream(const GemmBf16Params& p_in, hipStream_t st) {
   GemmBf16Params p = p_in;
-  if (p.group_m <= 0) p.group_m = g_gemm_bf16_group_m > 0 ? g_gemm_bf16_group_m : 8;
+  if (p.group_m <= 0) p.group_m = g_gemm_bf16_group_m > 0 ? g_gemm_bf16_group_m % 1000 : 8;
+  if (p.group_m <= 0) p.group_m = 8;
   const long long tiles = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  {   // de-phasing of the workgroups (see the kernel): `phases` start times a fraction of a tile period apart (the period estimated
+      // from the measured ~2300 cycles per k-tile).  It costs the last phase's delay at the end of the launch, so only launches with
+      // many tiles per workgroup take it: measured +3..7 % at 12 and 16 tiles per CU (K = 768), -5 % at 4 (K = 3072).
+    int phases = tiles >= 8ll * num_cus() ? 8 : 1;
+    KNOB_IF(g_gemm_bf16_group_m >= 1000) phases = g_gemm_bf16_group_m / 1000;
+    p.stagger = phases;
+    p.stagger_cycles = phases > 1 ? (long long)((p.K + 63) / 64) * 2300 / phases : 0;
+  }
   DGVIT_CHECK_ARG(tiles < (1ll << 30), "gemm_bf16: too many tiles");
   DGVIT_CHECK_ARG((long long)258 * p.ldc * 4 < (1ll << 31) && (long long)258 * p.ldc2 * 2 < (1ll << 31), "gemm_bf16: output leading dimension too large");
   DGVIT_CHECK_ARG(EPI != BEPI_GELU2_BF16 || p.ldc2 == p.ldc, "gemm_bf16: the GELU epilogue with a pre-activation copy needs ldc2 == ldc");
@@ -358,7 +459,7 @@ int gemm_bf16_stream(int epi, const GemmBf16Params& p, hipStream_t st) {
   if (g_gemm_diag && (epi == BEPI_BF16 || epi == BEPI_GELU_BF16)) {
 #define DGVIT_SD(D)                                                                        \
   if (g_gemm_diag == D) return epi == BEPI_BF16 ? launch_stream<BEPI_BF16, D>(p, st) : launch_stream<BEPI_GELU_BF16, D>(p, st);
-    DGVIT_SD(1) DGVIT_SD(2) DGVIT_SD(4) DGVIT_SD(8) DGVIT_SD(10) DGVIT_SD(14) DGVIT_SD(18) DGVIT_SD(30) DGVIT_SD(32) DGVIT_SD(40) DGVIT_SD(44) DGVIT_SD(16)
+    DGVIT_SD(1) DGVIT_SD(2) DGVIT_SD(4) DGVIT_SD(8) DGVIT_SD(10) DGVIT_SD(14) DGVIT_SD(18) DGVIT_SD(30) DGVIT_SD(32) DGVIT_SD(40) DGVIT_SD(44) DGVIT_SD(16) DGVIT_SD(72) DGVIT_SD(73) DGVIT_SD(74) DGVIT_SD(76) DGVIT_SD(88) DGVIT_SD(128) DGVIT_SD(256) DGVIT_SD(384) DGVIT_SD(200) DGVIT_SD(328)
 #undef DGVIT_SD
     return dgvit_set_error(DGVIT_ERR_ARG, "gemm_bf16_stream: no timing variant %d", g_gemm_diag);
   }

@@ -1004,9 +1004,9 @@ def test_direct_gemm_epilogue_stays_inside_c(layout, epi, M, N, K, ldc):
         buf = torch.full((pad + M * ldc + pad,), 555.0, device="cuda")
         buf2 = torch.full((pad + M * ldc + pad,), 555.0, device="cuda")
         C, C2 = buf[pad:pad + M * ldc].view(M, ldc), buf2[pad:pad + M * ldc].view(M, ldc)
-        # diag 0: the product library's direct epilogue (split off only matters for the equality with the LDS-image form below,
-        # these shapes do not split); diag 8: the LDS-image epilogue forced in the diagnostic library
-        with knobs(gemm_diagnostics=diag, gemm_split=1 if diag == 0 else 0) as klib:
+        # diag 0: the direct epilogue, diag 8: the LDS-image epilogue forced; both in the diagnostic library with the in-launch
+        # split off (a split tile sums its k-slices in another order, which is not the comparison made here)
+        with knobs(force_diag=True, gemm_diagnostics=diag, gemm_split=0) as klib:
             rc = klib.dgvit_gemm(layout, epi, A.data_ptr(), K, B.data_ptr(), K if layout == 0 else N, C.data_ptr(), ldc, M, N, K,
                                  bias.data_ptr() if bias is not None else None, res.data_ptr() if res is not None else None, N,
                                  C2.data_ptr() if epi == 1 else None, ldc, aux.data_ptr() if aux is not None else None, N,

@@ -13,10 +13,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 440
 lib = dgvit_amd.diagnostic_library().__enter__()
 T = B * 197
 g = torch.Generator(device="cuda").manual_seed(0)
-ARMS = [("ring (old)", 256256, 0), ("stream", 256257, 0), ("hot source", 256257, 1), ("no dma", 256257, 2), ("no frag reads", 256257, 4),
-        ("no epilogue", 256257, 8), ("no dma, no epilogue", 256257, 10), ("no dma/reads/epi", 256257, 14), ("no barrier (dma off)", 256257, 18),
-        ("mfma only", 256257, 2 + 4 + 8 + 16), ("no mfma", 256257, 32), ("no mfma, no epilogue", 256257, 40), ("dma only", 256257, 32 + 4 + 8),
-        ("stream again", 256257, 0), ("ring again", 256256, 0)]
+ARMS = [("ring (old)", 256256, 0), ("stream", 256257, 0), ("main loop only (no epilogue)", 256257, 72), ("main loop, no dma", 256257, 74),
+        ("DMA amid MFMAs", 256257, 128), ("DMA slots by wave group", 256257, 256), ("both", 256257, 384),
+        ("main loop, DMA amid MFMAs", 256257, 200), ("main loop, slots by group", 256257, 328), ("stream again", 256257, 0)]
 
 
 def timeit(fn, iters=20, warm=3):
@@ -44,4 +43,10 @@ for name, (m, n, k, epi) in {"qkv": (T, 2304, 768, 0), "qkv-f32out": (T, 2304, 7
         ms = timeit(lambda: F.op_gemm_bf16(epi, x, w, bias=bias))
         print(f"{name} ({m}, {n}, {k}) {arm:24s} {ms * 1e3:8.1f} us  {2.0 * m * n * k / ms / 1e9:8.1f} TFLOP/s-equivalent", flush=True)
     lib.dgvit_set_gemm_diagnostics(0)
+    for phases in ():
+        lib.dgvit_set_gemm_bf16_group_m(8 + 1000 * phases)
+        lib.dgvit_set_gemm_bf16_tile(256257)
+        ms = timeit(lambda: F.op_gemm_bf16(epi, x, w, bias=bias))
+        print(f"{name} ({m}, {n}, {k}) stagger {phases:2d} phases        {ms * 1e3:8.1f} us  {2.0 * m * n * k / ms / 1e9:8.1f} TFLOP/s", flush=True)
+    lib.dgvit_set_gemm_bf16_group_m(8)
     lib.dgvit_set_gemm_bf16_tile(0)
