@@ -53,6 +53,85 @@ __device__ __forceinline__ void stage_rows_tr(unsigned char* img, const bf16_t* 
   }
 }
 
+
+// One key tile of the online softmax on a transposed score tile (a lane owns one query: 16 of its 32 keys in s0, the other 16 in the
+// lane 32 away).  In: raw scores q.k; out: s0 = un-normalised probabilities exp2(score * sc - m), l and o brought to the running
+// maximum m.  The kernel is bound by exactly this VALU work (MFMA-busy 0.15), so: the scale is folded into the exponent's fma
+// (max of the raw scores, scaled once per row); keys >= N are masked in the last tile only; and the accumulator rescale is DEFERRED
+// (cdna_hip_programming.md T13): m only moves when some query's tile maximum exceeds it by more than 2^DEFER in probability, so
+// after the first tile the 32-register multiply of o almost never runs.  Probabilities then reach 2^DEFER instead of 1 -- the same
+// relative precision in bf16, sums in fp32; the normalisation by l at the end is exact either way.
+#define DGVIT_ATTN_DEFER 4.0f
+template <int NT>
+__device__ __forceinline__ void softmax_step(f32x16 (&s0)[NT], float& m, float& l, f32x16 (&o)[2], float sc, int kt, int nkt, int N, int h) {
+  if (kt + NT == nkt && (N & 31)) {   // uniform: only the last tile has keys past N
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((nkt - 1) * 32 + acc_row(r, h) >= N) s0[NT - 1][r] = -INFINITY;
+  }
+  float mt = s0[0][0];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s0[t][r]);
+  mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * sc;         // (sc > 0; every tile holds at least one real key: finite)
+  float alpha = 1.f;
+  if (!__all(mt - m <= DGVIT_ATTN_DEFER)) {            // wave-uniform; always taken in the first tile (m = -inf)
+    const float mn = fmaxf(m, mt);
+    alpha = __builtin_amdgcn_exp2f(m - mn);            // first tile: exp2(-inf) = 0 (l and o are 0 there)
+    m = mn;
+    if (kt > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[0][r] *= alpha;
+        o[1][r] *= alpha;
+      }
+    }
+  }
+  float ts = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pr = __builtin_amdgcn_exp2f(fmaf(s0[t][r], sc, -m));
+      s0[t][r] = pr;
+      ts += pr;
+    }
+  ts += __shfl_xor(ts, 32, 64);
+  l = l * alpha + ts;
+}
+
+// NT (1 or 2) key tiles of one query tile: S^T = K Q^T (independent accumulator chains), the softmax step over all of them, O^T += V^T P^T
+template <int NT>
+__device__ __forceinline__ void attn_key_tiles(const unsigned char* Ks, const unsigned char* Vs, const bf16x8 (&qf)[4], float& m, float& l, f32x16 (&o)[2],
+                                               float sc, int kt, int nkt, int N, int li, int h, int lane, unsigned fsw) {
+  f32x16 s0[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s0[t][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + ((kt + t) * 32 + li) * 128 + (((2 * s + h) ^ fsw) * 16));
+      s0[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], s0[t], 0, 0, 0);
+    }
+  softmax_step<NT>(s0, m, l, o, sc, kt, nkt, N, h);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    bf16x8 pf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[s][j] = (__bf16)s0[t][8 * s + j];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vs, (kt + t) * 32, dt, s, lane), pf[s], o[dt], 0, 0, 0);
+  }
+}
+
 template <int NW>
 __global__ void __launch_bounds__(64 * NW) attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                 float* __restrict__ lse, int N, int H, float scale, int nq) {
@@ -117,54 +196,9 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_bf16_kernel(const bf16_t* __
       o[0][r] = 0.f;
       o[1][r] = 0.f;
     }
-    for (int kt = 0; kt < nkt; ++kt) {
-      f32x16 s0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s0[r] = 0.f;
-      const unsigned char* krow = Ks + (kt * 32 + li) * 128;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(krow + (((2 * s + h) ^ fsw) * 16));
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], s0, 0, 0, 0);
-      }
-      float mt = -INFINITY;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + acc_row(r, h);
-        const float v = key < N ? s0[r] * sc : -INFINITY;
-        s0[r] = v;
-        mt = fmaxf(mt, v);
-      }
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float mn = fmaxf(m, mt);                       // every tile holds at least one real key: finite
-      const float alpha = __builtin_amdgcn_exp2f(m - mn);  // first tile: exp2(-inf) = 0
-      float ts = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pr = __builtin_amdgcn_exp2f(s0[r] - mn);
-        s0[r] = pr;
-        ts += pr;
-      }
-      ts += __shfl_xor(ts, 32, 64);
-      l = l * alpha + ts;
-      m = mn;
-      if (kt > 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          o[0][r] *= alpha;
-          o[1][r] *= alpha;
-        }
-      }
-      bf16x8 pf[2];
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[s][j] = (__bf16)s0[8 * s + j];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vs, kt * 32, dt, s, lane), pf[s], o[dt], 0, 0, 0);
-    }
+    int kt = 0;
+    for (; kt + 2 <= nkt; kt += 2) attn_key_tiles<2>(Ks, Vs, qf, m, l, o, sc, kt, nkt, N, li, h, lane, fsw);   // two key tiles at a time: twice
+    if (kt < nkt) attn_key_tiles<1>(Ks, Vs, qf, m, l, o, sc, kt, nkt, N, li, h, lane, fsw);                   // the independent work per dependent chain
     if (q < nq) {
       const float inv = 1.f / l;
       bf16_t* orow = out + ((long long)b * N + q) * I + hd * DH;
@@ -178,6 +212,113 @@ __global__ void __launch_bounds__(64 * NW) attn_fwd_bf16_kernel(const bf16_t* __
       if (lse && h == 0) lse[((long long)b * H + hd) * N + q] = m + __builtin_amdgcn_logf(l);   // base-2 log-sum-exp
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, persistent form
+// The per-(frame, head) kernel above is latency-bound: a workgroup stages 50 KB, waits, computes, stores, and only two of them
+// fit a CU (175 us per launch at BASELINE config 5, 3 TB/s -- its HBM time is ~100 us).  Here one workgroup per CU walks items
+// (frame, head) = id, id + grid, ... and the K / V / Q row images of item i + 1 are brought in by LDS-DMA (`buffer_load ... lds`,
+// 8 rows x 128 bytes per instruction: whole lines, no registers) WHILE item i is computed: two K and two V buffers of 256 rows
+// (32 KB each) and one Q buffer, all 160 KB of LDS.  Per item two barriers: after every wave has its Q fragments (the Q buffer
+// is free for the next item's DMA), and after the compute (the next item has landed -- the loader wave waited for it -- and this
+// item's K / V buffers are free; the compute waves' output stores simply stay in flight).
+// Rows >= N read zero through the buffer range check (V must be finite there: its probabilities are exact zeros).
+typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
+template <bool HAS_LSE>
+__global__ void __launch_bounds__(512) attn_fwd_bf16_stream_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse,
+                                                                   int N, int H, float scale, int nq, int nitems) {
+  constexpr int DH = 64, IMG = 256 * 128;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int nkt = (N + 31) / 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  const int I = H * DH;
+  const unsigned ldb = 3u * (unsigned)I * 2u;          // bytes between token rows of qkv
+  const float sc = scale * DGVIT_LOG2E;
+  unsigned char* Qs = smem + 4 * IMG;
+  // DMA lane geometry: instruction j (0..3) of a wave fills rows 64 j + 8 wave + (lane >> 3); physical chunk lane & 7 holds logical
+  // chunk (lane & 7) ^ f(row): f = (row >> 1) & 7 for the K / Q images, ((row >> 1) & 1) << 2 for V.  (row >> 1) & 7 = (4 (wave & 1)
+  // + (lane >> 4)) & 7 and (row >> 1) & 1 = (lane >> 4) & 1 for every j.
+  // Wave 7 never has a query tile (N <= 224: at most seven), so it is the LOADER: it issues all 96 DMA instructions of the next item
+  // (12 shares x 8), the compute waves none -- an LDS-DMA instruction blocks its wave for ~100 cycles, 12 of them in front of every
+  // item's first MFMA was a tenth of the item.
+  const unsigned cv = (unsigned)((lane & 7) ^ (((lane >> 4) & 1) << 2)), dstep = 64u * ldb;
+  auto issue_item = [&](int item, int buf, int sw) {
+    const int drow = 8 * sw + (lane >> 3);
+    const unsigned ck = (unsigned)((lane & 7) ^ ((4 * (sw & 1) + (lane >> 4)) & 7));
+    const unsigned offk = (unsigned)drow * ldb + ck * 16u, offv = (unsigned)drow * ldb + cv * 16u;
+    // (past the last item every lane is out of range: zeros into a free buffer, the same instruction count)
+    const bool live = item < nitems;
+    const int b = live ? item / H : 0, hd = live ? item % H : 0;
+    const bf16_t* base = qkv + (long long)b * N * (3ll * I) + hd * DH;
+    const int bytes = live ? (int)((unsigned)(N - 1) * ldb + 128u) : 0;
+    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base + I), 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base + 2 * I), 0, bytes, 0x00020000);
+    unsigned char* kd = smem + buf * IMG + sw * 1024, *vd = smem + (2 + buf) * IMG + sw * 1024, *qd = Qs + sw * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (attn_lds_ptr_t)(kd + j * 8192), 16, offk + j * dstep, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (attn_lds_ptr_t)(vd + j * 8192), 16, offv + j * dstep, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (attn_lds_ptr_t)(qd + j * 8192), 16, offk + j * dstep, 0, 0, 0);
+  };
+  const unsigned fsw = (unsigned)((li >> 1) & 7);
+  const int nqt = (nq + 31) / 32;
+  issue_item(blockIdx.x, 0, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x, buf ^= 1) {
+    const unsigned char* Ks = smem + buf * IMG, *Vs = smem + (2 + buf) * IMG;
+    const int b = item / H, hd = item % H;
+    // this wave's query fragments (waves beyond the last query tile read tile 0: harmless)
+    const int qt = wave < nqt ? wave : 0;
+    bf16x8 qf[4];
+    {
+      const unsigned char* qrow = Qs + (qt * 32 + li) * 128;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + (((2 * s + h) ^ fsw) * 16));
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();           // every wave holds its Q fragments: the Q buffer may take the next item
+    if (wave == 7) {
+      for (int sw = 0; sw < 8; ++sw) issue_item(item + (int)gridDim.x, buf ^ 1, sw);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    // output window of this item: rows past nq are dropped by the range check, every store below is issued by every lane
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + (long long)b * N * I + hd * DH, 0, (int)((unsigned)(nq - 1) * (unsigned)I * 2u + 128u), 0x00020000);
+    if (wave < nqt) {
+      const int q = qt * 32 + li;
+      float m = -INFINITY, l = 0.f;
+      f32x16 o[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        o[0][r] = 0.f;
+        o[1][r] = 0.f;
+      }
+      int kt = 0;
+      for (; kt + 2 <= nkt; kt += 2) attn_key_tiles<2>(Ks, Vs, qf, m, l, o, sc, kt, nkt, N, li, h, lane, fsw);
+      if (kt < nkt) attn_key_tiles<1>(Ks, Vs, qf, m, l, o, sc, kt, nkt, N, li, h, lane, fsw);
+      const float inv = 1.f / l;
+      const unsigned orow = (unsigned)q * (unsigned)I * 2u;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          fx4 v = {o[dt][4 * c] * inv, o[dt][4 * c + 1] * inv, o[dt][4 * c + 2] * inv, o[dt][4 * c + 3] * inv};
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, __builtin_convertvector(v, bf16x4)), ro, orow + (unsigned)(dt * 32 + 8 * c + 4 * h) * 2u, 0, 0);
+        }
+      if constexpr (HAS_LSE) {
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(lse + ((long long)b * H + hd) * N, 0, nq * 4, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m + __builtin_amdgcn_logf(l)), rl, h == 0 ? (unsigned)q * 4u : 0x80000000u, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();   // the next item is complete in LDS (the loader waited for it); this item's K / V buffers are free
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -430,8 +571,25 @@ int attention_fwd_bf16(const bf16_t* qkv, bf16_t* out, float* lse, int B, int N,
   const float scale = 1.0f / sqrtf((float)dh);
   const double flops = 4.0 * (double)nq * N * dh * H * B;
   const int slot = profile_begin(PROF_ATTN_FWD, flops, st);
-  // one wave per 32-query tile: 8 waves when there are more than 4 tiles (N = 197: 7 tiles), else 4
-  if ((nq + 31) / 32 > 4)
+  // many items of more than four query tiles (BASELINE config 5: N = 197, 5280 items): the persistent kernel with LDS-DMA prefetch
+  const long long items = (long long)B * H;
+  if ((N + 31) / 32 > 4 && items >= 512 && 3ll * H * dh * 2 * 256 < (1ll << 31)) {
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    static int cached_cus = 0;
+    if (!cached_cus) cached_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cus = cached_cus;
+    static DeviceOnce once;
+    if (const unsigned long long bit = once.pending()) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_stream_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_bf16_stream_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return dgvit_set_error(DGVIT_ERR_HIP, "attention_fwd_bf16: cannot raise the dynamic LDS limit");
+      once.mark(bit);
+    }
+    const unsigned grid = (unsigned)(items < cus ? items : cus);
+    if (lse) hipLaunchKernelGGL((attn_fwd_bf16_stream_kernel<true>), dim3(grid), dim3(512), 160 * 1024, st, qkv, out, lse, N, H, scale, nq, (int)items);
+    else hipLaunchKernelGGL((attn_fwd_bf16_stream_kernel<false>), dim3(grid), dim3(512), 160 * 1024, st, qkv, out, lse, N, H, scale, nq, (int)items);
+  } else if ((nq + 31) / 32 > 4)
     hipLaunchKernelGGL((attn_fwd_bf16_kernel<8>), dim3((unsigned)((long long)B * H)), dim3(512), lds, st, qkv, out, lse, N, H, scale, nq);
   else
     hipLaunchKernelGGL((attn_fwd_bf16_kernel<4>), dim3((unsigned)((long long)B * H)), dim3(256), lds, st, qkv, out, lse, N, H, scale, nq);

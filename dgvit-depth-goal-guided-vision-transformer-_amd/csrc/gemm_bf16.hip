@@ -88,7 +88,7 @@ __device__ __forceinline__ void epilogue(const GemmBf16Params& p, unsigned char*
           *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = __builtin_convertvector(v, bf16x4);
         } else if (EPI == BEPI_GELU_BF16 || EPI == BEPI_GELU2_BF16) {
           if (EPI == BEPI_GELU2_BF16) *reinterpret_cast<bf16x4*>(p.C2 + (long long)gm * p.ldc2 + gn) = __builtin_convertvector(v, bf16x4);
-          fx4 g = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+          fx4 g = gelu_bf16x4(v);
           *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.C) + crow * p.ldc + gn) = __builtin_convertvector(g, bf16x4);
         } else {  // BEPI_DGELU_BF16
           const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.aux + (long long)gm * p.ldaux + gn);
@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
             } else if (EPI == BEPI_GELU_BF16 || EPI == BEPI_GELU2_BF16) {
               if (EPI == BEPI_GELU2_BF16)   // ldc2 == ldc (checked at launch): the pre-activation copy shares the tile-relative offset
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(v, bf16x4)), rsX, coff, 0, 0);
-              fx4 g = {gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+              fx4 g = gelu_bf16x4(v);
               __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2v, __builtin_convertvector(g, bf16x4)), rsC, coff, 0, 0);
             } else {  // BEPI_DGELU_BF16
               const bf16x4 a = __builtin_bit_cast(bf16x4, auxv[EPI == BEPI_DGELU_BF16 ? i : 0][half * NQ + q]);

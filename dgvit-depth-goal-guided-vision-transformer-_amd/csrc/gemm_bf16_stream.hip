@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
             acc[i][j] = zero4;      // the next tile accumulates from zero
             const unsigned a = w_off + (((unsigned)(4 * j + q) ^ wsw) << 3);
             if constexpr (TWO) *reinterpret_cast<bf16x4*>(stg + 16384 + a) = __builtin_convertvector(v, bf16x4);   // pre-activation -> chunks 2, 3
-            if constexpr (EPI == BEPI_GELU_BF16 || EPI == BEPI_GELU2_BF16) v = fx4{gelu_erf(v[0]), gelu_erf(v[1]), gelu_erf(v[2]), gelu_erf(v[3])};
+            if constexpr (EPI == BEPI_GELU_BF16 || EPI == BEPI_GELU2_BF16) v = gelu_bf16x4(v);
             *reinterpret_cast<bf16x4*>(stg + (TWO ? 0 : buf * 16384) + a) = __builtin_convertvector(v, bf16x4);
           }
         };
