@@ -54,6 +54,9 @@ struct GemmBf16Params {
   long long slab_stride;        //             (BEPI_F32_PLAIN only; the slabs are summed by reduce_slabs)
   int group_m;                  // row panels per walk group (0 = default); see tile_mn in gemm_bf16_ring_kernel
   int stagger; long long stagger_cycles;   // stream kernel: start phases of the workgroups and cycles between them (set at launch)
+#ifdef DGVIT_DIAG
+  long long* diag_stamps;   // stream kernel, timing variant 512: [workgroup][wave][tile < 8][8] s_memtime stamps (tools/bf16_stream_stamps.py)
+#endif
   int tn;                       // 1: A is (K, M) with row stride lda, B is (K, N): C = A^T B (BEPI_F32_PLAIN, 256 x 256 tile)
 };
 

@@ -64,6 +64,24 @@ __device__ __forceinline__ void wait_vmcnt() {
 template <int VAR, int PAR>
 __device__ __forceinline__ void sched_half() {
   __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+  if (VAR == 3) {          // leading wave of a SIMD pair: matrix work first (fragment reads between the blocks), the four DMAs at the end
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x10, 4, 0);
+    return;
+  }
+  if (VAR == 4) {          // its partner: DMAs and fragment reads first, matrix work behind them
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x8, 32, 0);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     if (VAR == 1 && (i & 1) == PAR) {   // the DMA in the middle of the block's MFMAs, away from the fragment reads
@@ -85,9 +103,14 @@ __device__ __forceinline__ void sched_half() {
 // (compile-time variants: a run-time test around every MFMA wrecks the very schedule being measured)
 #define SDIAG(b) ((DIAG & (b)) != 0)
 
-template <int EPI, int DIAG = 0>
-__global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Params p, int ntiles) {
+template <int EPI, int DIAG, int ROLE>     // ROLE: 0 every wave the same schedule; 1 / 2 leading / trailing wave of a SIMD pair (timing variant 256)
+__device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles) {
+  constexpr int HVAR = ROLE == 1 ? 3 : ROLE == 2 ? 4 : SDIAG(128) ? 1 : 0;
   constexpr bool OUT_F32 = EPI == BEPI_F32_PLAIN;
+  // Output stores are non-temporal (aux bit 1): C is never read again by this launch and is larger than the L2s, so letting it allocate there
+  // only evicts the A / B k-slices that the neighbouring tiles are about to re-read (measured at B = 440: QKV 313 -> 278 us, fc1 420 -> 394 us,
+  // fc2 -- 3 column tiles, few stores -- unchanged; timing variant 2048 restores ordinary stores)
+  constexpr int ST_AUX = SDIAG(2048) ? 0 : 2;
   constexpr int ES = OUT_F32 ? 4 : 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -176,6 +199,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
     const long long wait = (long long)phase * p.stagger_cycles;
     while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
   }
+  if constexpr (SDIAG(1024)) {
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // timing variant: static priority for the second-dispatched half
+  }
   // prologue: two k-tiles in flight, the first one landed, its first half in registers
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -198,6 +224,19 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
   }
   wait_lgkm0();
 
+#ifdef DGVIT_DIAG
+  long long st_start = 0, st_wait = 0, st_h1 = 0, st_h2 = 0, st_t = 0;
+  int st_tile = 0;
+  if constexpr (SDIAG(512)) st_start = st_t = __builtin_amdgcn_s_memtime();
+#define STAMP_ADD(acc_)                                          \
+  if constexpr (SDIAG(512)) {                                    \
+    const long long now_ = __builtin_amdgcn_s_memtime();         \
+    acc_ += now_ - st_t;                                         \
+    st_t = now_;                                                 \
+  }
+#else
+#define STAMP_ADD(acc_)
+#endif
   while (ctile < ntiles) {
     const int s1 = cslot + 1 >= NSLOT ? cslot + 1 - NSLOT : cslot + 1, s2 = cslot + 2 >= NSLOT ? cslot + 2 - NSLOT : cslot + 2,
               s3 = cslot + 3 >= NSLOT ? cslot + 3 - NSLOT : cslot + 3;
@@ -215,12 +254,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
         if constexpr (!SDIAG(4)) fa1[i] = *reinterpret_cast<const bf16x8*>(sA + i * 2048);
         if ((i & 1) == PAR) dma_a(i >> 1);
       }
-      sched_half<(SDIAG(128) ? 1 : 0), PAR>();
+      sched_half<HVAR, PAR>();
       };
-      if (SDIAG(256) && grp) first_half(std::integral_constant<int, 0>{});
-      else first_half(std::integral_constant<int, 1>{});
+      first_half(std::integral_constant<int, 1>{});
     }
     next_slot();
+    STAMP_ADD(st_h1)
     wait_lgkm0();   // this wave holds every fragment of k-tile t ...
     // ... and its shares of pieces 2 t + 2, 2 t + 3 (k-tile t + 1) have landed: everything but the piece issued during this half.
     // Right after an epilogue the tile's NST stores are younger than those pieces too and may stay in flight (every one of them is
@@ -234,6 +273,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!SDIAG(16)) __builtin_amdgcn_s_barrier();        // k-tile t + 1 is complete; the slots of k-tile t are free
+    STAMP_ADD(st_wait)
     __builtin_amdgcn_sched_barrier(0);
     // ---- second half: MFMAs on (fa1, fb1); first-half fragments of k-tile t + 1 -> (fa0, fb0); piece 2 t + 5 into a slot of k-tile t
     if (EPI != BEPI_F32_PLAIN && p.bias && ct == nkt - 1) {
@@ -259,14 +299,14 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
         if constexpr (!SDIAG(4)) fa0[i] = *reinterpret_cast<const bf16x8*>(nA + i * 2048);
         if ((i & 1) == PAR) dma_b(i >> 1);
       }
-      sched_half<(SDIAG(128) ? 1 : 0), PAR>();
+      sched_half<HVAR, PAR>();
       };
-      if (SDIAG(256) && grp) second_half(std::integral_constant<int, 0>{});
-      else second_half(std::integral_constant<int, 1>{});
+      second_half(std::integral_constant<int, 1>{});
     }
     next_slot();
     next_ktile();
     wait_lgkm0();
+    STAMP_ADD(st_h2)
     __builtin_amdgcn_sched_barrier(0);
     cslot = s2;
     int cnkt = nkt;
@@ -327,42 +367,47 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
           wait_lgkm0();
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int u = 0; u < 4; ++u, off += rowstep) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v[u]), rsC, off, 0, 0);
+          for (int u = 0; u < 4; ++u, off += rowstep) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v[u]), rsC, off, 0, ST_AUX);
         }
       } else {
         // bf16 outputs are staged as finished bf16 values: a 16 x 64 block is 2 KB = two of the wave's chunks (row r in chunk r >> 3,
-        // 8-byte pieces swizzled by ^ ((r >> 1) & 7): conflict-free for the ds_write_b64 of the accumulator layout and the ds_read_b64
-        // of the row layout), so two blocks alternate and block i + 1 is written while block i's read is in flight: one LDS round
-        // trip per block on the critical path instead of two.  (GELU with a pre-activation copy stages both outputs, one pair of
-        // chunks each, without the overlap.)
+        // 16-byte pieces swizzled by ^ ((r >> 1) & 7): conflict-free for the ds_write_b64 of the accumulator layout -- a lane's 8 bytes
+        // are half of piece (4 j + q) >> 1 -- and for the ds_read_b128 of the row layout), read back as 8 lanes x 16 bytes per row so
+        // that one global store instruction covers EIGHT whole 128-byte rows (half the store and LDS-read instructions of 8-byte
+        // pieces).  Two blocks alternate and block i + 1 is written while block i's read is in flight: one LDS round trip per block on
+        // the critical path instead of two.  (GELU with a pre-activation copy stages both outputs, one pair of chunks each, without
+        // the overlap.)
         constexpr bool TWO = EPI == BEPI_GELU2_BF16;
-        const unsigned w_off = (unsigned)(l15 >> 3) * 8192u + (unsigned)(l15 & 7) * 128u;       // + ((4 j + q) ^ ((l15 >> 1) & 7)) * 8
         const unsigned wsw = (unsigned)((l15 >> 1) & 7);
+        const unsigned w_off = (unsigned)(l15 >> 3) * 8192u + (unsigned)(l15 & 7) * 128u + (unsigned)(q & 1) * 8u;   // + (((4 j + q) >> 1) ^ wsw) * 16
         auto stage = [&](int i, int buf) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             fx4 v = acc[i][j] + bv[j];
             acc[i][j] = zero4;      // the next tile accumulates from zero
-            const unsigned a = w_off + (((unsigned)(4 * j + q) ^ wsw) << 3);
+            const unsigned a = w_off + (((unsigned)(2 * j + (q >> 1)) ^ wsw) << 4);
             if constexpr (TWO) *reinterpret_cast<bf16x4*>(stg + 16384 + a) = __builtin_convertvector(v, bf16x4);   // pre-activation -> chunks 2, 3
             if constexpr (EPI == BEPI_GELU_BF16 || EPI == BEPI_GELU2_BF16) v = gelu_bf16x4(v);
             *reinterpret_cast<bf16x4*>(stg + (TWO ? 0 : buf * 16384) + a) = __builtin_convertvector(v, bf16x4);
           }
         };
-        auto rd_off = [&](int u) {   // row 4 u + rr of the block, piece rc
-          const int row = 4 * u + rr;
-          return (unsigned)(row >> 3) * 8192u + (unsigned)(row & 7) * 128u + (((unsigned)rc ^ (unsigned)((row >> 1) & 7)) << 3);
-        };
+        const int r8 = lane >> 3, k8 = lane & 7;                                      // read-back: row 8 u + r8 of the block, 16-byte piece k8
+        const unsigned rd0 = (unsigned)r8 * 128u + (((unsigned)k8 ^ (unsigned)((r8 >> 1) & 3)) << 4);      // u = 0: swizzle (r8 >> 1) & 7
+        const unsigned rd1 = 8192u + (unsigned)r8 * 128u + (((unsigned)k8 ^ (unsigned)(4 + ((r8 >> 1) & 3))) << 4);   // u = 1: rows 8..15
+        unsigned off8 = (unsigned)(wr * 128 + r8) * (unsigned)p.ldc * 2u + (n0 + wc * 64 + 8 * k8 < p.N ? (unsigned)(wc * 64 + 8 * k8) * 2u : OOB);
+        const unsigned rowstep8 = 8u * (unsigned)p.ldc * 2u;
         stage(0, 0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           wait_lgkm0();     // block i is staged (wave-private region: its own writes are all it waits for)
           __builtin_amdgcn_wave_barrier();
-          u32x2v v[4], v2[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            v[u] = *reinterpret_cast<const u32x2v*>(stg + (TWO ? 0 : (i & 1) * 16384) + rd_off(u));
-            if constexpr (TWO) v2[u] = *reinterpret_cast<const u32x2v*>(stg + 16384 + rd_off(u));
+          u32x4v v[2], v2[2];
+          const unsigned char* src = stg + (TWO ? 0 : (i & 1) * 16384);
+          v[0] = *reinterpret_cast<const u32x4v*>(src + rd0);
+          v[1] = *reinterpret_cast<const u32x4v*>(src + rd1);
+          if constexpr (TWO) {
+            v2[0] = *reinterpret_cast<const u32x4v*>(stg + 16384 + rd0);
+            v2[1] = *reinterpret_cast<const u32x4v*>(stg + 16384 + rd1);
           }
           if constexpr (!TWO) {
             if (i + 1 < 8) stage(i + 1, (i + 1) & 1);     // into the other pair of chunks, under this block's read latency
@@ -370,9 +415,9 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
           wait_lgkm0();
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int u = 0; u < 4; ++u, off += rowstep) {
-            if constexpr (TWO) __builtin_amdgcn_raw_buffer_store_b64(v2[u], rsC2, off, 0, 0);   // ldc2 == ldc (checked at launch): same offset
-            __builtin_amdgcn_raw_buffer_store_b64(v[u], rsC, off, 0, 0);
+          for (int u = 0; u < 2; ++u, off8 += rowstep8) {
+            if constexpr (TWO) __builtin_amdgcn_raw_buffer_store_b128(v2[u], rsC2, off8, 0, ST_AUX);   // ldc2 == ldc (checked at launch): same offset
+            __builtin_amdgcn_raw_buffer_store_b128(v[u], rsC, off8, 0, ST_AUX);
           }
           if constexpr (TWO) {
             if (i + 1 < 8) stage(i + 1, 0);
@@ -389,11 +434,33 @@ __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Par
           acc[i][j] = zero4;
         }
     }   // (SDIAG(8): epilogue skipped)
+#ifdef DGVIT_DIAG
+    if constexpr (SDIAG(512)) {
+      const long long now = __builtin_amdgcn_s_memtime();
+      if (lane == 0 && st_tile < 8 && p.diag_stamps) {
+        long long* o = p.diag_stamps + ((((long long)blockIdx.x * 8 + wave) * 8) + st_tile) * 8;
+        o[0] = st_start; o[1] = st_t; o[2] = now; o[3] = st_wait; o[4] = st_h1; o[5] = st_h2; o[6] = __builtin_amdgcn_s_memrealtime(); o[7] = ctile;
+      }
+      ++st_tile;
+      st_start = st_t = __builtin_amdgcn_s_memtime();
+      st_wait = st_h1 = st_h2 = 0;
+    }
+#endif
     ct = 0;
     ctile += gridDim.x;
     after_epi = !SDIAG(8);
   }
   wait_vmcnt<0>();   // the trailing (all-zero) LDS-DMAs must land before the workgroup gives its LDS back
+}
+
+template <int EPI, int DIAG = 0>
+__global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Params p, int ntiles) {
+  if constexpr (SDIAG(256)) {
+    if (threadIdx.x < 256) stream_body<EPI, DIAG, 1>(p, ntiles);     // waves 0-3: one per SIMD
+    else stream_body<EPI, DIAG, 2>(p, ntiles);                       // waves 4-7: their partners
+  } else {
+    stream_body<EPI, DIAG, 0>(p, ntiles);
+  }
 }
 
 int num_cus() {
@@ -410,6 +477,9 @@ int num_cus() {
 template <int EPI, int DIAG = 0>
 int launch_stream(const GemmBf16Params& p_in, hipStream_t st) {
   GemmBf16Params p = p_in;
+#ifdef DGVIT_DIAG
+  p.diag_stamps = g_gemm_bf16_stamps;
+#endif
   if (p.group_m <= 0) p.group_m = g_gemm_bf16_group_m > 0 ? g_gemm_bf16_group_m % 1000 : 8;
   if (p.group_m <= 0) p.group_m = 8;
   const long long tiles = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
@@ -446,6 +516,7 @@ int launch_stream(const GemmBf16Params& p_in, hipStream_t st) {
 bool gemm_bf16_stream_supports(int epi, const GemmBf16Params& p) {
   if (p.tn || p.ksplit > 1 || p.c_rgrp > 0 || p.res_mod > 0 || p.res) return false;
   if (!(epi == BEPI_BF16 || epi == BEPI_GELU_BF16 || epi == BEPI_GELU2_BF16 || epi == BEPI_F32_PLAIN)) return false;
+  if (epi != BEPI_F32_PLAIN && (p.N % 8 || p.ldc % 8 || (epi == BEPI_GELU2_BF16 && p.ldc2 % 8))) return false;   // 16-byte bf16 store pieces
   return p.K % 8 == 0 && p.N % 4 == 0;
 }
 
@@ -459,7 +530,7 @@ int gemm_bf16_stream(int epi, const GemmBf16Params& p, hipStream_t st) {
   if (g_gemm_diag && (epi == BEPI_BF16 || epi == BEPI_GELU_BF16)) {
 #define DGVIT_SD(D)                                                                        \
   if (g_gemm_diag == D) return epi == BEPI_BF16 ? launch_stream<BEPI_BF16, D>(p, st) : launch_stream<BEPI_GELU_BF16, D>(p, st);
-    DGVIT_SD(1) DGVIT_SD(2) DGVIT_SD(4) DGVIT_SD(8) DGVIT_SD(10) DGVIT_SD(14) DGVIT_SD(18) DGVIT_SD(30) DGVIT_SD(32) DGVIT_SD(40) DGVIT_SD(44) DGVIT_SD(16) DGVIT_SD(72) DGVIT_SD(73) DGVIT_SD(74) DGVIT_SD(76) DGVIT_SD(88) DGVIT_SD(128) DGVIT_SD(256) DGVIT_SD(384) DGVIT_SD(200) DGVIT_SD(328)
+    DGVIT_SD(1) DGVIT_SD(2) DGVIT_SD(4) DGVIT_SD(8) DGVIT_SD(10) DGVIT_SD(14) DGVIT_SD(18) DGVIT_SD(30) DGVIT_SD(32) DGVIT_SD(40) DGVIT_SD(41) DGVIT_SD(44) DGVIT_SD(16) DGVIT_SD(72) DGVIT_SD(73) DGVIT_SD(74) DGVIT_SD(76) DGVIT_SD(88) DGVIT_SD(128) DGVIT_SD(256) DGVIT_SD(512) DGVIT_SD(768) DGVIT_SD(1024) DGVIT_SD(1536) DGVIT_SD(1280) DGVIT_SD(2048) DGVIT_SD(2049) DGVIT_SD(3072)
 #undef DGVIT_SD
     return dgvit_set_error(DGVIT_ERR_ARG, "gemm_bf16_stream: no timing variant %d", g_gemm_diag);
   }

@@ -118,7 +118,7 @@ def test_gelu_epilogue_against_the_erf_form(F, tile, step):
     close(y2, ref, atol=2.6e-5, rtol=2 ** -8, msg="gelu (with copy)")
     assert torch.equal(pre.double().cpu(), x[:, None].expand(256, 256))
     yc = y.double().cpu()[:, 0]
-    assert torch.equal(yc[x >= 8], x[x >= 8]) and bool((yc[x <= -8].abs() < 1e-12).all()) and yc[x == 0].item() == 0.0
+    assert torch.equal(yc[x >= 8], x[x >= 8]) and bool((yc[x <= -8].abs() < 1e-10).all()) and yc[x == 0].item() == 0.0
 
 
 def test_gemm_bf16_identity_asymmetric(F, mfma16):

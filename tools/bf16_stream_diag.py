@@ -13,9 +13,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 440
 lib = dgvit_amd.diagnostic_library().__enter__()
 T = B * 197
 g = torch.Generator(device="cuda").manual_seed(0)
-ARMS = [("ring (old)", 256256, 0), ("stream", 256257, 0), ("main loop only (no epilogue)", 256257, 72), ("main loop, no dma", 256257, 74),
-        ("DMA amid MFMAs", 256257, 128), ("DMA slots by wave group", 256257, 256), ("both", 256257, 384),
-        ("main loop, DMA amid MFMAs", 256257, 200), ("main loop, slots by group", 256257, 328), ("stream again", 256257, 0)]
+ARMS = [("stream (warm-up)", 256257, 0), ("stream", 256257, 0), ("non-temporal stores", 256257, 2048), ("hot source", 256257, 1), ("hot source, nt stores", 256257, 2049),
+        ("stream again", 256257, 0), ("non-temporal stores again", 256257, 2048), ("nt stores + priority", 256257, 3072)]
 
 
 def timeit(fn, iters=20, warm=3):
@@ -31,7 +30,7 @@ def timeit(fn, iters=20, warm=3):
     return t0.elapsed_time(t1) / iters
 
 
-for name, (m, n, k, epi) in {"qkv": (T, 2304, 768, 0), "qkv-f32out": (T, 2304, 768, 4), "fc1": (T, 3072, 768, 1), "fc2": (T, 768, 3072, 0)}.items():
+for name, (m, n, k, epi) in {"qkv": (T, 2304, 768, 0), "fc1": (T, 3072, 768, 1), "fc2": (T, 768, 3072, 0)}.items():
     x = torch.randn(m, k, device="cuda", generator=g).to(torch.bfloat16)
     w = (torch.randn(n, k, device="cuda", generator=g) * k ** -0.5).to(torch.bfloat16)
     bias = torch.randn(n, device="cuda", generator=g)
