@@ -30,9 +30,14 @@ class dgvit_mlp_desc(Structure):
                 ("towers", c_int), ("heads3", c_int)]
 
 
+class dgvit_grad_events(Structure):
+    """include/dgvit_hip.h: events recorded by dgvit_got_backward[_bf16]_ev where a group of gradients is final"""
+    _fields_ = [("n_layers", c_int), ("layer", POINTER(c_void_p)), ("head", c_void_p)]
+
+
 NUM_GLOBAL_PARAMS = 4
 PARAMS_PER_LAYER = 11
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _P, _I, _LL, _F, _ULL = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 _CFG = POINTER(dgvit_config)
@@ -48,6 +53,10 @@ SIGNATURES = {
     "dgvit_got_backward_scratch_floats": (_LL, [_CFG, _I]),
     "dgvit_got_forward": (_I, [_CFG, _TABLE, _P, _P, _P, _P, _LL, _I, _I, _F, _ULL, _P, _P]),
     "dgvit_got_backward": (_I, [_CFG, _TABLE, _TABLE, _P, _P, _P, _LL, _P, _LL, _I, _F, _ULL, _P, _P]),
+    "dgvit_got_backward_ev": (_I, [_CFG, _TABLE, _TABLE, _P, _P, _P, _LL, _P, _LL, _I, _F, _ULL, _P, _P, POINTER(dgvit_grad_events)]),
+    "dgvit_event_create": (_I, [POINTER(c_void_p)]),
+    "dgvit_event_destroy": (_I, [_P]),
+    "dgvit_stream_wait_event": (_I, [_P, _P]),
     "dgvit_linear_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dgvit_linear_backward_scratch_floats": (_LL, [_I, _I, _I]),
     "dgvit_linear_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _LL, _I, _I, _I, _I, _P]),
@@ -88,6 +97,7 @@ SIGNATURES = {
     "dgvit_got_forward_bf16": (_I, [_CFG, _TABLE, _P, _P, _P, _P, _P, _LL, _I, _I, _F, _ULL, _P, _P]),
     "dgvit_got_bf16_backward_scratch_bytes": (_LL, [_CFG, _I]),
     "dgvit_got_backward_bf16": (_I, [_CFG, _TABLE, _P, _TABLE, _P, _P, _P, _P, _LL, _P, _LL, _I, _F, _ULL, _P, _P]),
+    "dgvit_got_backward_bf16_ev": (_I, [_CFG, _TABLE, _P, _TABLE, _P, _P, _P, _P, _LL, _P, _LL, _I, _F, _ULL, _P, _P, POINTER(dgvit_grad_events)]),
     "dgvit_wgrad_bf16_scratch_floats": (_LL, [_I, _I, _I]),
     "dgvit_wgrad_bf16": (_I, [_P, _P, _P, _P, _P, _LL, _I, _I, _I, _P]),
     "dgvit_cast_f32_bf16": (_I, [_P, _P, _LL, _P]),

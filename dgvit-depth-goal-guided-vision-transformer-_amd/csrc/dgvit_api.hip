@@ -482,14 +482,52 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
   return rmsnorm_fwd(x, (long long)d.N * d.D, params[P_RMS], feat, d.B, d.D, st);
 }
 
+// gradient-ready events (dgvit_grad_events): recorded on the caller's stream where a group of parameter gradients is final
+static int check_events(const dgvit_grad_events* ev, int depth) {
+  if (!ev) return DGVIT_OK;
+  DGVIT_CHECK_ARG(ev->n_layers == depth, "dgvit_grad_events: n_layers %d != depth %d", ev->n_layers, depth);
+  DGVIT_CHECK_ARG(ev->layer, "dgvit_grad_events: layer table is null");
+  return DGVIT_OK;
+}
+static int mark_ready(void* event, hipStream_t st) {
+  if (event) HIP_TRY(hipEventRecord((hipEvent_t)event, st));
+  return DGVIT_OK;
+}
+
+extern "C" int dgvit_event_create(void** event) {
+  DGVIT_CHECK_ARG(event, "dgvit_event_create: null pointer");
+  hipEvent_t e;
+  HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  *event = (void*)e;
+  return DGVIT_OK;
+}
+extern "C" int dgvit_event_destroy(void* event) {
+  if (event) HIP_TRY(hipEventDestroy((hipEvent_t)event));
+  return DGVIT_OK;
+}
+extern "C" int dgvit_stream_wait_event(void* stream, void* event) {
+  DGVIT_CHECK_ARG(event, "dgvit_stream_wait_event: null event");
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+  return DGVIT_OK;
+}
+
 extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* params, float* const* grads, const float* dfeat,
                                   float* dgoal, const float* ws, long long ws_floats, float* scratch, long long scratch_floats,
                                   int batch, float keep, unsigned long long seed, const unsigned long long* seed_dev,
                                   void* stream) {
+  return dgvit_got_backward_ev(cfg, params, grads, dfeat, dgoal, ws, ws_floats, scratch, scratch_floats, batch, keep, seed, seed_dev, stream,
+                               nullptr);
+}
+
+extern "C" int dgvit_got_backward_ev(const dgvit_config* cfg, const float* const* params, float* const* grads, const float* dfeat,
+                                     float* dgoal, const float* ws, long long ws_floats, float* scratch, long long scratch_floats,
+                                     int batch, float keep, unsigned long long seed, const unsigned long long* seed_dev,
+                                     void* stream, const dgvit_grad_events* events) {
   hipStream_t st = (hipStream_t)stream;
   Dims d;
   TRY(make_dims(cfg, batch, d));
   DGVIT_CHECK_ARG(params && grads && dfeat && ws && scratch, "dgvit_got_backward: null pointer");
+  TRY(check_events(events, cfg->depth));
   const Ws w = make_ws(d, 1);
   const Bs s = make_bs(d);
   if (ws_floats < w.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "backward workspace %lld < %lld floats", ws_floats, w.total);
@@ -533,6 +571,7 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
     HIP_TRY(hipMemsetAsync(dx, 0, sizeof(float) * d.T * d.D, st));
     TRY(rmsnorm_bwd(dfeat, xl, (long long)d.N * d.D, params[P_RMS], dx, (long long)d.N * d.D, grads[P_RMS], part, d.B, d.D, st));
   }
+  if (events) TRY(mark_ready(events->head, st));
 
   for (int i = d.L - 1; i >= 0; --i) {
     const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
@@ -605,6 +644,7 @@ extern "C" int dgvit_got_backward(const dgvit_config* cfg, const float* const* p
     TRY(fork());
     TRY(reduce_group_flush(grp, sw));
     TRY(join());
+    if (events) TRY(mark_ready(events->layer[i], st));    // every gradient of block i is final in stream order
   }
   // ---- token assembly: x0 = dropout(cat(goal, patches W^T + b) + pos)
   if (keep < 1.f) TRY(dropout_inplace(dx, d.T * d.D, seed, seed_dev, keep, st));
@@ -1255,11 +1295,21 @@ extern "C" int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* con
                                        float* const* grads, const float* dfeat, float* dgoal, const float* img,
                                        const void* workspace, long long ws_bytes, void* scratch, long long scratch_bytes, int batch,
                                        float keep, unsigned long long seed, const unsigned long long* seed_dev, void* stream) {
+  return dgvit_got_backward_bf16_ev(cfg, params, wpack, grads, dfeat, dgoal, img, workspace, ws_bytes, scratch, scratch_bytes, batch, keep, seed,
+                                    seed_dev, stream, nullptr);
+}
+
+extern "C" int dgvit_got_backward_bf16_ev(const dgvit_config* cfg, const float* const* params, const unsigned short* wpack,
+                                          float* const* grads, const float* dfeat, float* dgoal, const float* img,
+                                          const void* workspace, long long ws_bytes, void* scratch, long long scratch_bytes, int batch,
+                                          float keep, unsigned long long seed, const unsigned long long* seed_dev, void* stream,
+                                          const dgvit_grad_events* events) {
   hipStream_t st = (hipStream_t)stream;
   Dims d;
   TRY(make_dims(cfg, batch, d));
   TRY(check_bf16_dims(d));
   DGVIT_CHECK_ARG(params && wpack && grads && dfeat && img && workspace && scratch, "dgvit_got_backward_bf16: null pointer");
+  TRY(check_events(events, cfg->depth));
   const Wsb w = make_wsb(d, 1);
   const Wp wp = make_wp(d);
   const Bsb s = make_bsb(d);
@@ -1297,6 +1347,7 @@ extern "C" int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* con
     HIP_TRY(hipMemsetAsync(dx, 0, sizeof(float) * d.T * d.D, st));
     TRY(rmsnorm_bwd(dfeat, xl, (long long)d.N * d.D, params[P_RMS], dx, (long long)d.N * d.D, grads[P_RMS], part, d.B, d.D, st));
   }
+  if (events) TRY(mark_ready(events->head, st));
   TRY(cast_f32_bf16(dx, dxh, d.T * d.D, st));
 
   for (int i = d.L - 1; i >= 0; --i) {
@@ -1340,6 +1391,7 @@ extern "C" int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* con
     }
     TRY(layernorm_bwd_bf16(dln, xin, (const float*)(lb + w.mean1), (const float*)(lb + w.rstd1), lp[L_LN1W], dx2, dx, dxh, lg[L_LN1W],
                            lg[L_LN1B], part, T, d.D, 1, st));
+    if (events) TRY(mark_ready(events->layer[i], st));
   }
   // ---- token assembly: x0 = dropout(cat(goal, patches W^T + b) + pos): fp32, as dgvit_got_backward
   if (keep < 1.f) TRY(dropout_inplace(dx, d.T * d.D, seed, seed_dev, keep, st));

@@ -57,7 +57,7 @@ def make_config(image, patch, dim, depth, heads, dim_head, mlp_dim) -> dgvit_con
 
 
 # ------------------------------------------------------------------------------------------------ encoder
-_N_NONPARAM_INPUTS = 6   # img, goal, cfg_tuple, keep, seed, need_grad precede *params in _GoTEncoder.apply
+_N_NONPARAM_INPUTS = 7   # img, goal, cfg_tuple, keep, seed, need_grad, grad_hook precede *params in _GoTEncoder.apply
 
 
 def _flat_grads(params, needs, dev):
@@ -75,6 +75,47 @@ def _flat_grads(params, needs, dev):
     return [flat[o:o + p.numel()].view_as(p) if need else None for o, p, need in zip(offs, params, needs)]
 
 
+_EVENT_POOL = {}    # (device index, depth) -> [event handles]: re-recorded by every backward that has a gradient-ready hook
+
+
+def _layer_events(dev, depth):
+    """`depth` hipEvent_t handles (dgvit_event_create) for the gradient-ready events of one backward on `dev`."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), depth)
+    evs = _EVENT_POOL.get(key)
+    if evs is None:
+        lib = _lib.load()
+        evs = []
+        with torch.cuda.device(dev):
+            for _ in range(depth):
+                h = ctypes.c_void_p()
+                _lib.check(lib.dgvit_event_create(ctypes.byref(h)), "dgvit_event_create")
+                evs.append(h.value)
+        _EVENT_POOL[key] = evs
+    return evs
+
+
+def _grad_events(depth, evs):
+    """the dgvit_grad_events argument (and the ctypes array it points to, which must outlive the call)"""
+    table = (ctypes.c_void_p * depth)(*evs)
+    return _lib.dgvit_grad_events(depth, table, None), table
+
+
+def _call_grad_hook(hook, grads, depth, evs):
+    """hook(flat gradient buffer, [(lo, hi) element range of block i's gradients for i = depth-1 .. 0], [their events]): the order in
+    which the backward finishes them.  Blocks whose parameters are all frozen are left out."""
+    live = [g for g in grads if g is not None]
+    if not live:
+        return
+    flat = torch.empty(0, dtype=torch.float32, device=live[0].device).set_(live[0].untyped_storage(), 0, (live[0].untyped_storage().nbytes() // 4,))
+    groups, events = [], []
+    for i in range(depth - 1, -1, -1):
+        gs = [g for g in grads[_lib.NUM_GLOBAL_PARAMS + _lib.PARAMS_PER_LAYER * i:_lib.NUM_GLOBAL_PARAMS + _lib.PARAMS_PER_LAYER * (i + 1)] if g is not None]
+        if gs:
+            groups.append((min(g.storage_offset() for g in gs), max(g.storage_offset() + g.numel() for g in gs)))
+            events.append(evs[i])
+    hook(flat, groups, events)
+
+
 def _grad_table(grads):
     return (ctypes.c_void_p * len(grads))(*[0 if g is None else g.data_ptr() for g in grads])
 
@@ -90,7 +131,7 @@ def _take_workspace(ctx, what):
 
 class _GoTEncoder(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, goal, cfg_tuple, keep, seed, need_grad, *params):
+    def forward(ctx, img, goal, cfg_tuple, keep, seed, need_grad, grad_hook, *params):
         lib = _lib.load()
         cfg = dgvit_config(*cfg_tuple)
         img, goal = _dev(img, "img"), _dev(goal, "goal")
@@ -119,6 +160,7 @@ class _GoTEncoder(torch.autograd.Function):
             ctx.cfg_tuple, ctx.keep, ctx.seed, ctx.batch = cfg_tuple, float(keep), seed_val, B
             ctx.seed_dev = seed_dev
             ctx.ws = ws
+            ctx.grad_hook = grad_hook
             ctx.save_for_backward(*params)
         return feat
 
@@ -137,20 +179,28 @@ class _GoTEncoder(torch.autograd.Function):
         dgoal = torch.empty(B, cfg.dim, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         nsc = lib.dgvit_got_backward_scratch_floats(ctypes.byref(cfg), B)
         scratch = torch.empty(nsc, dtype=torch.float32, device=dev)
+        evs = _layer_events(dev, cfg.depth) if ctx.grad_hook is not None else None
+        events, keep_alive = _grad_events(cfg.depth, evs) if evs else (None, None)
         with torch.cuda.device(dev):
-            rc = lib.dgvit_got_backward(ctypes.byref(cfg), _table(params), _grad_table(grads), _ptr(dfeat), _ptr(dgoal), _ptr(ws),
-                                        ws.numel(), _ptr(scratch), nsc, B, ctx.keep, ctx.seed, _ptr(ctx.seed_dev), _stream())
+            rc = lib.dgvit_got_backward_ev(ctypes.byref(cfg), _table(params), _grad_table(grads), _ptr(dfeat), _ptr(dgoal), _ptr(ws),
+                                           ws.numel(), _ptr(scratch), nsc, B, ctx.keep, ctx.seed, _ptr(ctx.seed_dev), _stream(),
+                                           ctypes.byref(events) if events is not None else None)
         _lib.check(rc, "dgvit_got_backward")
         ctx.ws = None
-        return (None, dgoal, None, None, None, None, *grads)
+        if evs:     # the kernels are queued, not finished: the hook orders its own stream behind the events (parallel.GradSync)
+            _call_grad_hook(ctx.grad_hook, grads, cfg.depth, evs)
+        return (None, dgoal, None, None, None, None, None, *grads)
 
 
-def got_encoder(img, goal, cfg_tuple, params, dropout_keep=1.0, dropout_seed=0):
-    """feat (B, D) = GoT.forward(img (B,H,W), goal (B,D)); params in the table order of dgvit_hip.h."""
+def got_encoder(img, goal, cfg_tuple, params, dropout_keep=1.0, dropout_seed=0, grad_hook=None):
+    """feat (B, D) = GoT.forward(img (B,H,W), goal (B,D)); params in the table order of dgvit_hip.h.
+    ``grad_hook(flat, ranges, events)``: called inside the backward, right after its kernels are queued, with the flat gradient buffer,
+    the element range of every transformer block's gradients (last block first) and the HIP event recorded where that range is final
+    (include/dgvit_hip.h: dgvit_grad_events) -- parallel.GradSync(overlap=True) starts the blocks' all-reduces there."""
     if img.shape[0] == 0:
         return _empty_batch((0, int(cfg_tuple[4])), [img, goal, *params])
     need_grad = torch.is_grad_enabled() and (goal.requires_grad or any(p.requires_grad for p in params))
-    return _GoTEncoder.apply(img, goal, tuple(cfg_tuple), dropout_keep, dropout_seed, need_grad, *params)
+    return _GoTEncoder.apply(img, goal, tuple(cfg_tuple), dropout_keep, dropout_seed, need_grad, grad_hook, *params)
 
 
 # ------------------------------------------------------------------------------------------------ CNN feature stack
@@ -691,7 +741,7 @@ class _GoTEncoderBf16(torch.autograd.Function):
     """GoT.forward in the bf16 configuration as one autograd node (dgvit_got_forward_bf16 / dgvit_got_backward_bf16)."""
 
     @staticmethod
-    def forward(ctx, img, goal, cfg_tuple, keep, seed, need_grad, weights, *params):
+    def forward(ctx, img, goal, cfg_tuple, keep, seed, need_grad, grad_hook, weights, *params):
         lib = _lib.load()
         cfg = dgvit_config(*cfg_tuple)
         img, goal = _dev(img, "img"), _dev(goal, "goal")
@@ -719,6 +769,7 @@ class _GoTEncoderBf16(torch.autograd.Function):
         if need_grad:
             ctx.cfg_tuple, ctx.keep, ctx.seed, ctx.batch = cfg_tuple, float(keep), seed_val, B
             ctx.seed_dev, ctx.ws, ctx.wpack, ctx.img = seed_dev, ws, wpack, img
+            ctx.grad_hook = grad_hook
             ctx.save_for_backward(*params)
         return feat
 
@@ -734,18 +785,22 @@ class _GoTEncoderBf16(torch.autograd.Function):
         dgoal = torch.empty(B, cfg.dim, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
         nsc = lib.dgvit_got_bf16_backward_scratch_bytes(ctypes.byref(cfg), B)
         scratch = torch.empty(nsc, dtype=torch.uint8, device=dev)
+        evs = _layer_events(dev, cfg.depth) if ctx.grad_hook is not None else None
+        events, keep_alive = _grad_events(cfg.depth, evs) if evs else (None, None)
         with torch.cuda.device(dev):
-            rc = lib.dgvit_got_backward_bf16(ctypes.byref(cfg), _table(params), _ptr(ctx.wpack), _grad_table(grads), _ptr(dfeat), _ptr(dgoal),
-                                             _ptr(ctx.img), _ptr(ws), ws.numel(), _ptr(scratch), nsc, B, ctx.keep, ctx.seed,
-                                             _ptr(ctx.seed_dev), _stream())
+            rc = lib.dgvit_got_backward_bf16_ev(ctypes.byref(cfg), _table(params), _ptr(ctx.wpack), _grad_table(grads), _ptr(dfeat), _ptr(dgoal),
+                                                _ptr(ctx.img), _ptr(ws), ws.numel(), _ptr(scratch), nsc, B, ctx.keep, ctx.seed,
+                                                _ptr(ctx.seed_dev), _stream(), ctypes.byref(events) if events is not None else None)
         _lib.check(rc, "dgvit_got_backward_bf16")
         ctx.ws = ctx.wpack = ctx.img = None
-        return (None, dgoal, None, None, None, None, None, *grads)
+        if evs:
+            _call_grad_hook(ctx.grad_hook, grads, cfg.depth, evs)
+        return (None, dgoal, None, None, None, None, None, None, *grads)
 
 
-def got_encoder_bf16(img, goal, cfg_tuple, params, weights: Bf16Weights, dropout_keep=1.0, dropout_seed=0):
+def got_encoder_bf16(img, goal, cfg_tuple, params, weights: Bf16Weights, dropout_keep=1.0, dropout_seed=0, grad_hook=None):
     """GoT.forward in the bf16 configuration (bf16 storage of GEMM operands, fp32 master parameters and gradients)."""
     if img.shape[0] == 0:
         return _empty_batch((0, int(cfg_tuple[4])), [img, goal, *params])
     need_grad = torch.is_grad_enabled() and (goal.requires_grad or any(p.requires_grad for p in params))
-    return _GoTEncoderBf16.apply(img, goal, tuple(cfg_tuple), dropout_keep, dropout_seed, need_grad, weights, *params)
+    return _GoTEncoderBf16.apply(img, goal, tuple(cfg_tuple), dropout_keep, dropout_seed, need_grad, grad_hook, weights, *params)

@@ -122,6 +122,7 @@ class GoT(nn.Module):
                      1 if pool == 'mean' else 0, 0)       # last entry: schedule flags (set_schedule)
         self.compute_dtype = torch.float32
         self._bf16_weights = F_.Bf16Weights()
+        self._grad_hook = None     # set by parallel.GradSync(overlap=True): called inside the backward with the gradient-ready events
         self.register_load_state_dict_post_hook(_weights_loaded)
 
     def __deepcopy__(self, memo):
@@ -183,5 +184,5 @@ class GoT(nn.Module):
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())   # CPU generator: follows torch.manual_seed, no device sync
         params = self.param_table()
         if self.compute_dtype == torch.bfloat16:
-            return F_.got_encoder_bf16(img, goal, self._cfg, params, self._bf16_weights, keep, seed)
-        return F_.got_encoder(img, goal, self._cfg, params, keep, seed)
+            return F_.got_encoder_bf16(img, goal, self._cfg, params, self._bf16_weights, keep, seed, grad_hook=self._grad_hook)
+        return F_.got_encoder(img, goal, self._cfg, params, keep, seed, grad_hook=self._grad_hook)

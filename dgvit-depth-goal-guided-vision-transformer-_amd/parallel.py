@@ -8,6 +8,12 @@ finds such shared buffers through the gradients' storages and all-reduces them i
 collectives sized for xGMI's per-link ring bandwidth, no flatten/unflatten copies.  The remaining small
 gradients (head Linears) are coalesced into one extra buffer.  Parameters that never get a gradient
 (``cls_token``, ``mlp_head.*``, the dead ``conv1-3``) simply have ``grad is None`` and are skipped.
+
+``overlap=True``: the encoder backward records a HIP event where each transformer block's gradients are final
+(include/dgvit_hip.h: dgvit_grad_events; blocks finish last-to-first).  GradSync then queues that block's all-reduce on a side
+stream behind its event while the backward's kernels for the earlier blocks are still running, and ``sync()`` only exchanges
+what is left (embedding, final norm, heads) and makes the caller's stream wait for everything.  On RCCL the reduction is
+``ReduceOp.AVG`` (no separate 1/world pass); gloo has no AVG, so CPU runs keep sum + scale.
 """
 from typing import Iterable, List
 
@@ -17,9 +23,11 @@ import torch.distributed as dist
 
 class GradSync:
     def __init__(self, modules: Iterable[torch.nn.Module], process_group=None, bucket_bytes: int = 64 << 20,
-                 force_collective: bool = False):
+                 force_collective: bool = False, overlap: bool = False):
         """``force_collective``: issue the all-reduce even in a world of one rank (a 1-rank RCCL group reduces a buffer onto
-        itself) -- lets a single-GPU box exercise the exact code path the 8-GPU run takes."""
+        itself) -- lets a single-GPU box exercise the exact code path the 8-GPU run takes.
+        ``overlap``: start each transformer block's all-reduce from inside the encoder backward (see the module docstring).
+        Needs ``zero_grad()`` of this class (or ``set_to_none``) before every backward, and one backward per ``sync()``."""
         self.params: List[torch.nn.Parameter] = []
         self.modules = list(modules)
         self.force_collective = bool(force_collective)
@@ -32,6 +40,17 @@ class GradSync:
         self.group = process_group
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._last_numel = 0
+        self.overlap = bool(overlap)
+        self._side = {}          # device -> side stream the early all-reduces are queued on
+        self._early = []         # (storage data_ptr, lo, hi, work handle) of this step's early all-reduces
+        self.early_launches = 0  # all-reduces started from inside a backward so far (tests, timelines)
+        self.on_block_queued = None   # optional callable(side_stream): after each block's all-reduces were queued (tools/overlap_timeline.py)
+        if self.overlap:
+            from .goalformer import GoT
+            for m in self.modules:
+                for sub in m.modules():
+                    if isinstance(sub, GoT):
+                        sub._grad_hook = self._on_grads_ready
 
     @property
     def world(self) -> int:
@@ -84,18 +103,71 @@ class GradSync:
             shared.append(flat)
         return shared, loose
 
+    def _active(self) -> bool:
+        return self.world > 1 or self.force_collective
+
+    def _reduce_op(self):
+        """(op, scale afterwards?): RCCL averages in the collective; gloo only sums"""
+        if dist.get_backend(self.group) == "nccl":
+            return dist.ReduceOp.AVG, False
+        return dist.ReduceOp.SUM, True
+
+    def _on_grads_ready(self, flat, ranges, events) -> None:
+        """functional's gradient-ready hook: runs inside the encoder backward, after its kernels were queued.  ``ranges[k]`` of
+        ``flat`` is final once ``events[k]`` has happened; its all-reduce goes to the side stream behind that event."""
+        if not self._active():
+            return
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("GradSync: torch.distributed is not initialised")
+        key = flat.untyped_storage().data_ptr()
+        if any(e[0] == key for e in self._early):
+            raise RuntimeError("GradSync(overlap=True): this gradient buffer is already being reduced")
+        from . import _lib
+        lib = _lib.load()
+        dev = flat.device
+        side = self._side.get(dev)
+        if side is None:
+            side = self._side[dev] = torch.cuda.Stream(device=dev)
+        op, _ = self._reduce_op()
+        with torch.cuda.device(dev), torch.cuda.stream(side):
+            for (lo, hi), ev in zip(ranges, events):
+                _lib.check(lib.dgvit_stream_wait_event(side.cuda_stream, ev), "dgvit_stream_wait_event")
+                for off in range(lo, hi, self.bucket_elems):
+                    end = min(hi, off + self.bucket_elems)
+                    h = dist.all_reduce(flat[off:end], op=op, group=self.group, async_op=True)   # RCCL's stream waits for `side`
+                    self._early.append((key, off, end, h))
+                    self.early_launches += 1
+                if self.on_block_queued is not None:
+                    self.on_block_queued(side)
+
     def sync(self) -> None:
-        """All-reduce(sum)/world the gradients; call once after backward."""
+        """All-reduce the gradients to their mean over the ranks; call once after backward.  With ``overlap`` the transformer
+        blocks' shares are already on their way (``_on_grads_ready``): only the rest is exchanged here, then the caller's
+        stream waits for all of it."""
         shared, loose = self._regions()
         self._last_numel = sum(p.grad.numel() for p in self.params if p.grad is not None)
         if self._last_numel == 0:
             raise RuntimeError("GradSync: no parameter has a gradient; call after backward()")
-        w = self.world
-        if w == 1 and not self.force_collective:
+        if not self._active():
             return
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("GradSync: torch.distributed is not initialised")
-        handles, bufs = [], list(shared)
+        op, scale = self._reduce_op()
+        early, self._early = self._early, []
+        live = {g.untyped_storage().data_ptr() for g in shared}
+        for key, lo, hi, h in early:
+            if key not in live:     # autograd accumulated the new gradients into older .grad tensors: the early reduce missed them
+                raise RuntimeError("GradSync(overlap=True): a reduced gradient buffer is not the parameters' .grad -- call "
+                                   "GradSync.zero_grad() (grads set to None) before every backward")
+        handles, bufs = [h for _, _, _, h in early], []
+        for buf in shared:
+            key, base = buf.untyped_storage().data_ptr(), buf.storage_offset()
+            done = sorted((lo, hi) for k, lo, hi, _ in early if k == key)
+            pos = base
+            for lo, hi in done + [(base + buf.numel(), base + buf.numel())]:     # the gaps between the early ranges
+                if lo > pos:
+                    bufs.append(buf[pos - base:lo - base])
+                pos = max(pos, hi)
         small = None
         if loose:
             small = torch.cat([g.reshape(-1) for g in loose])
@@ -104,14 +176,16 @@ class GradSync:
             n = buf.numel()
             for off in range(0, n, self.bucket_elems):
                 chunk = buf[off:min(n, off + self.bucket_elems)]
-                handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                handles.append(dist.all_reduce(chunk, op=op, group=self.group, async_op=True))
         for h in handles:
             h.wait()
-        inv = 1.0 / w
-        for buf in shared:
-            buf.mul_(inv)
+        if scale:
+            inv = 1.0 / self.world
+            for buf in shared:
+                buf.mul_(inv)
+            if small is not None:
+                small.mul_(inv)
         if small is not None:
-            small.mul_(inv)
             off = 0
             for g in loose:
                 g.copy_(small[off:off + g.numel()].view_as(g))

@@ -24,7 +24,7 @@ extern "C" {
 #endif
 #pragma GCC visibility push(default)
 
-#define DGVIT_ABI_VERSION 6
+#define DGVIT_ABI_VERSION 7
 
 /* error codes */
 #define DGVIT_OK 0
@@ -112,6 +112,29 @@ int dgvit_got_backward(const dgvit_config* cfg, const float* const* params, floa
                        float* dgoal, const float* workspace, long long workspace_floats, float* scratch,
                        long long scratch_floats, int batch, float dropout_keep, unsigned long long dropout_seed,
                        const unsigned long long* dropout_seed_dev, void* stream);
+
+/* Gradient-ready events: the data-parallel gradient exchange (RCCL all-reduce, one bucket per transformer block) can start while the
+ * backward is still running on earlier blocks.  dgvit_got_backward_ev / dgvit_got_backward_bf16_ev are dgvit_got_backward /
+ * dgvit_got_backward_bf16 with one more argument: events the call RECORDS ON `stream` at the point where a group of parameter
+ * gradients is final (all split-K slab sums and LayerNorm partial sums included):
+ *   head      after the final-norm gradient (grads[3]), before the last block's backward;
+ *   layer[i]  after every gradient of transformer block i (grads[4 + 11 i .. 4 + 11 i + 10]); blocks finish in the order L-1 .. 0.
+ * The embedding gradients (grads[0..2]) are final when the call's work on `stream` is.  NULL entries are skipped; events == NULL is
+ * the plain call.  Events are hipEvent_t handles: the caller's own, or made by dgvit_event_create (timing disabled).  A consumer on
+ * another stream orders itself with dgvit_stream_wait_event (= hipStreamWaitEvent) -- host code never blocks.
+ * (The reference has no counterpart: torch DDP's bucket hooks on autograd, which one fused backward call bypasses.) */
+typedef struct dgvit_grad_events {
+  int n_layers;        /* must equal cfg->depth */
+  void* const* layer;  /* [n_layers] hipEvent_t or NULL */
+  void* head;          /* hipEvent_t or NULL */
+} dgvit_grad_events;
+int dgvit_event_create(void** event);
+int dgvit_event_destroy(void* event);
+int dgvit_stream_wait_event(void* stream, void* event);
+int dgvit_got_backward_ev(const dgvit_config* cfg, const float* const* params, float* const* grads, const float* dfeat,
+                          float* dgoal, const float* workspace, long long workspace_floats, float* scratch,
+                          long long scratch_floats, int batch, float dropout_keep, unsigned long long dropout_seed,
+                          const unsigned long long* dropout_seed_dev, void* stream, const dgvit_grad_events* events);
 
 /* ----------------------------------------------------------------------------------------------
  * Head Linears (got_sac_network.py:111,115-121,226,230-234,429,433-435):  y = act(x W^T + b)
@@ -291,6 +314,11 @@ int dgvit_got_backward_bf16(const dgvit_config* cfg, const float* const* params,
                             const float* dfeat, float* dgoal, const float* img, const void* workspace, long long workspace_bytes,
                             void* scratch, long long scratch_bytes, int batch, float dropout_keep, unsigned long long dropout_seed,
                             const unsigned long long* dropout_seed_dev, void* stream);
+/* ... with gradient-ready events (see dgvit_grad_events) */
+int dgvit_got_backward_bf16_ev(const dgvit_config* cfg, const float* const* params, const unsigned short* wpack, float* const* grads,
+                               const float* dfeat, float* dgoal, const float* img, const void* workspace, long long workspace_bytes,
+                               void* scratch, long long scratch_bytes, int batch, float dropout_keep, unsigned long long dropout_seed,
+                               const unsigned long long* dropout_seed_dev, void* stream, const dgvit_grad_events* events);
 /* operator-level entry points of the bf16 kernels (parity tests, benches) */
 /* dW (Mo, Ko) fp32 = dY^T X and db (Mo, may be NULL) = column sums of dY, for dY (T, Mo) and X (T, Ko) bf16, token-major
  * (Mo, Ko % 8 == 0): the TN layout of the ring GEMM (transposed LDS reads), split over tokens into fp32 slabs that are summed in

@@ -37,7 +37,7 @@ def test_library_exports_every_header_symbol(amd):
         assert hasattr(lib, name), f"libdgvit_hip.so does not export {name}"
         assert name in _lib.SIGNATURES, f"ctypes binding has no signature for {name}"
     assert sorted(_lib.SIGNATURES) == declared, "binding and header disagree"
-    assert lib.dgvit_abi_version() == 6
+    assert lib.dgvit_abi_version() == 7
     # the product library has no setters and none of the diagnostic entry points
     assert not [n for n in declared if n.startswith("dgvit_set_")]
     for name in _header_functions(DIAG_HEADER):

@@ -410,7 +410,8 @@ def test_canaries_linear(amd, M, N, K, act):
 
 
 # ------------------------------------------------------------------------------------------------ RCCL on one rank
-def test_gradsync_collective_branch_on_a_one_rank_rccl_group(amd):
+@pytest.mark.parametrize("overlap", [False, True], ids=["after-backward", "overlapped"])
+def test_gradsync_collective_branch_on_a_one_rank_rccl_group(amd, overlap):
     """backend "nccl" is RCCL on ROCm.  A one-rank group makes all_reduce the identity, so the collective branch of
     GradSync.sync() (buckets over the fused backward's flat gradient buffer, then /world) can run on this one-GPU box:
     gradients must come back unchanged, and FlatAdam must still pick the buffer up in place."""
@@ -430,7 +431,8 @@ def test_gradsync_collective_branch_on_a_one_rank_rccl_group(amd):
         m = _load_state(amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, **kw), O.make_params(O.policy_param_spec(cfg), 9)).eval().to("cuda")
         img, pstate, _, _ = (t.cuda() for t in O.make_inputs(cfg, 8, 9))
         opt = FlatAdam([m], lr=1e-3)
-        sync = GradSync([m], force_collective=True, bucket_bytes=64 << 10)      # small buckets: several collectives per buffer
+        # small buckets: several collectives per buffer; overlapped: ReduceOp.AVG all-reduces queued from inside the backward
+        sync = GradSync([m], force_collective=True, bucket_bytes=64 << 10, overlap=overlap)
         before = {k: p.detach().clone() for k, p in m.named_parameters()}
         sync.broadcast_parameters(0)
         for k, p in m.named_parameters():
@@ -438,6 +440,8 @@ def test_gradsync_collective_branch_on_a_one_rank_rccl_group(amd):
         sync.zero_grad()
         mean, log_std = m([img, pstate])
         ((mean ** 2).mean() + (log_std ** 2).mean()).backward()
+        assert sync.early_launches >= 2 * 18 if overlap else sync.early_launches == 0
+        torch.cuda.synchronize()      # (the early all-reduces of a one-rank group are identities: the copy below sees final values)
         ref = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
         sync.sync()
         torch.cuda.synchronize()
