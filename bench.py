@@ -242,13 +242,23 @@ def c5_bf16(dgvit_amd, lib, _lib, dev, batch=440, steps=10):
     dtb = (time.perf_counter() - t0) / 5
     train = {"frames_per_s": round(batch / dtb, 1), "ms_per_step": round(dtb * 1e3, 3), "tflops_dense": round(batch / dtb * 3 * fwd / 1e12, 1),
              "frac_of_bf16_peak": round(batch / dtb * 3 * fwd / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
+    c5_traffic, c5_tpath = None, None
+    try:   # bytes that left the L2s per stream-GEMM launch (tools/collect_profiles_c5.sh; FETCH_SIZE x2 + WRITE_SIZE, own --pmc passes)
+        import glob
+        c5_tpath = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c5_bf16_l2_miss_traffic.json")))[-1]
+        with open(c5_tpath) as f:
+            c5_traffic = json.load(f)["kernels"]["gemm_bf16_stream_kernel"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError, IndexError):
+        c5_tpath = None
     return {"workload": f"C5: GoT 224x224@16x16, L12 H12 D768 M3072 (N=197), forward, batch {batch}, bf16 storage / fp32 accumulate",
             "frames_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "dtype": "bf16",
             "tflops_dense": round(batch / dt * fwd / 1e12, 1), "frac_of_bf16_peak": round(batch / dt * fwd / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
             "batch": batch, "roofline": {"bound": "mfma", "kernel": "gemm_bf16_stream_kernel (+ ring kernel for the patch GEMM)", "achieved": round(gemm_tf, 1), "peak": PEAK_BF16_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(gemm_tf / PEAK_BF16_MFMA_TFLOPS, 4),
                          "avg_launch_ms": round(ms[0] / max(1, cnt[0]), 5), "launches_per_step": int(cnt_all[0] // steps),
-                         "launches_timed": int(cnt[0])},
+                         "launches_timed": int(cnt[0]), "traffic": c5_traffic,
+                         "traffic_note": "bytes beyond the L2s per launch at batch 440 (Infinity Cache + HBM; rocprofv3 --pmc FETCH_SIZE(x2) / WRITE_SIZE passes, "
+                                         + (os.path.relpath(c5_tpath, ROOT) if c5_tpath else "not collected") + "); algorithmic operands + outputs: 536 MB per launch on average"},
             "gemm_ms_per_step": round(per_step(0), 3), "attn_fwd_ms_per_step": round(per_step(1), 3),
             "norm_ms_per_step": round(per_step(3), 3), "fwd_bwd": train}
 

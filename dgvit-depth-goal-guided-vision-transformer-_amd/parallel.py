@@ -46,6 +46,13 @@ class GradSync:
         self.early_launches = 0  # all-reduces started from inside a backward so far (tests, timelines)
         self.on_block_queued = None   # optional callable(side_stream): after each block's all-reduces were queued (tools/overlap_timeline.py)
         if self.overlap:
+            import os
+            import warnings
+            if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
+                # measured (tools/overlap_queue_probe.py): with an RCCL process group alive and the HIP runtime's default of 4 hardware
+                # queues, work queued behind a gradient-ready event runs only after the whole backward -- correct, but not overlapped
+                warnings.warn("GradSync(overlap=True): export GPU_MAX_HW_QUEUES=8 (before the first HIP call) or the collectives' stream "
+                              "shares a hardware queue with the compute stream and nothing overlaps", RuntimeWarning, stacklevel=2)
             from .goalformer import GoT
             for m in self.modules:
                 for sub in m.modules():
