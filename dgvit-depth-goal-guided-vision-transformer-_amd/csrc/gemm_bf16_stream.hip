@@ -190,9 +190,9 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
   bool after_epi = false;
   constexpr int NST = EPI == BEPI_GELU2_BF16 ? 64 : 32;   // global stores per wave and tile
 
-  // De-phasing: every workgroup would otherwise reach its tile boundaries at the same moment (equal tiles, one start), and the chip's
-  // whole output of a round -- 128 KB per CU, 32 MB in all -- would hit the L2s and HBM as one burst while the operand stream
-  // waits behind it.  Workgroups sharing an XCD (ids 8 apart) start `stagger` phases apart, a fraction of a tile period each.
+  // De-phasing (timing knob of the diagnostic build; the launcher passes one phase): workgroups sharing an XCD (ids 8 apart) start
+  // `stagger` phases apart, a fraction of a tile period each, so that the chip's whole output of a round -- 128 KB per CU, 32 MB in
+  // all -- does not hit the L2s and HBM as one burst.  It paid with ordinary stores; with non-temporal ones lockstep is faster.
   if (p.stagger > 1) {
     const int phase = ((int)blockIdx.x >> 3) % p.stagger;
     const long long t0 = __builtin_amdgcn_s_memtime();
@@ -484,9 +484,11 @@ int launch_stream(const GemmBf16Params& p_in, hipStream_t st) {
   if (p.group_m <= 0) p.group_m = 8;
   const long long tiles = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   {   // de-phasing of the workgroups (see the kernel): `phases` start times a fraction of a tile period apart (the period estimated
-      // from the measured ~2300 cycles per k-tile).  It costs the last phase's delay at the end of the launch, so only launches with
-      // many tiles per workgroup take it: measured +3..7 % at 12 and 16 tiles per CU (K = 768), -5 % at 4 (K = 3072).
-    int phases = tiles >= 8ll * num_cus() ? 8 : 1;
+      // from the measured ~2300 cycles per k-tile).  With ordinary output stores 8 phases were worth +3..7 % at 12 and 16 tiles per CU
+      // (K = 768); since the stores are non-temporal, lockstep wins on every shape (QKV 253-269 vs 261-290 us, to_out 89.5 vs 93.5,
+      // fc1 385-390 vs 397-400, fc2 326 vs 360: workgroups that share an A panel or a B column fetch the same k-slices at the same
+      // time, profiles/r03_b_stream_gemm_phase_sweep.txt), so the default is one phase; the diagnostic build keeps the knob.
+    int phases = 1;
     KNOB_IF(g_gemm_bf16_group_m >= 1000) phases = g_gemm_bf16_group_m / 1000;
     p.stagger = phases;
     p.stagger_cycles = phases > 1 ? (long long)((p.K + 63) / 64) * 2300 / phases : 0;

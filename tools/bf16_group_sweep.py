@@ -19,9 +19,9 @@ for name, (m, n, k, epi) in {"qkv": (T, 2304, 768, 0), "out": (T, 768, 768, 0), 
     bias = torch.randn(n, device="cuda", generator=g)
     lib.dgvit_set_gemm_bf16_tile(256257)
     timeit(lambda: F.op_gemm_bf16(epi, x, w, bias=bias))
-    for gm in (8, 2, 4, 12, 16, 32, 64, 8):
-        for ph in (0,):
+    for gm in (8, 4):
+        for ph in (8, 1, 2, 4, 16, 8, 1):
             lib.dgvit_set_gemm_bf16_group_m(gm + 1000 * ph)
             ms = timeit(lambda: F.op_gemm_bf16(epi, x, w, bias=bias))
-            print(f"{name} group_m {gm:3d}  {ms*1e3:8.1f} us {2.0*m*n*k/ms/1e9:8.1f} TF", flush=True)
+            print(f"{name} group_m {gm:3d} phases {ph:2d}  {ms*1e3:8.1f} us {2.0*m*n*k/ms/1e9:8.1f} TF", flush=True)
     lib.dgvit_set_gemm_bf16_group_m(8)
