@@ -66,6 +66,18 @@ bool gemm_bf16_stream_supports(int epi, const GemmBf16Params& p);
 int gemm_bf16_stream(int epi, const GemmBf16Params& p, hipStream_t st);
 
 int cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t st);
+// several fp32 -> bf16 casts as ONE launch (weight packing): add segments, flush launches them (and a full table flushes itself)
+#define DGVIT_CAST_SEGMENTS 64
+struct CastBatch {
+  const float* src[DGVIT_CAST_SEGMENTS];
+  bf16_t* dst[DGVIT_CAST_SEGMENTS];
+  long long n4[DGVIT_CAST_SEGMENTS];
+  int first_block[DGVIT_CAST_SEGMENTS + 1];
+  int nseg;
+};
+void cast_batch_init(CastBatch& b);
+int cast_batch_add(CastBatch& b, const float* src, bf16_t* dst, long long n, hipStream_t st);
+int cast_batch_flush(CastBatch& b, hipStream_t st);
 int patchify_bf16(const float* img, bf16_t* patches, int B, int ih, int iw, int ph, int pw, hipStream_t st);
 int layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int T, int D,
                        float eps, int rs, hipStream_t st);

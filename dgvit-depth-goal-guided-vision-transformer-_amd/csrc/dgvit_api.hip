@@ -1165,14 +1165,21 @@ extern "C" int dgvit_got_pack_weights_bf16(const dgvit_config* cfg, const float*
   DGVIT_CHECK_ARG(params && wpack, "dgvit_got_pack_weights_bf16: null pointer");
   const Wp w = make_wp(d);
   if (wpack_elems < w.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "bf16 weight arena %lld < %lld elements", wpack_elems, w.total);
-  TRY(cast_f32_bf16(params[P_PW], wpack + w.patch, (long long)d.D * d.pd, st));
+  CastBatch cb;     // the straight copies of all layers go out as one launch (49 segments at depth 12)
+  cast_batch_init(cb);
+  TRY(cast_batch_add(cb, params[P_PW], wpack + w.patch, (long long)d.D * d.pd, st));
   for (int i = 0; i < d.L; ++i) {
     const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
     bf16_t* lw = wpack + w.layer0 + w.layer_elems * i;
-    TRY(cast_f32_bf16(lp[L_QKV], lw + w.qkv, (long long)3 * d.I * d.D, st));
-    TRY(cast_f32_bf16(lp[L_OUTW], lw + w.out, (long long)d.D * d.I, st));
-    TRY(cast_f32_bf16(lp[L_FC1W], lw + w.fc1, (long long)d.M * d.D, st));
-    TRY(cast_f32_bf16(lp[L_FC2W], lw + w.fc2, (long long)d.D * d.M, st));
+    TRY(cast_batch_add(cb, lp[L_QKV], lw + w.qkv, (long long)3 * d.I * d.D, st));
+    TRY(cast_batch_add(cb, lp[L_OUTW], lw + w.out, (long long)d.D * d.I, st));
+    TRY(cast_batch_add(cb, lp[L_FC1W], lw + w.fc1, (long long)d.M * d.D, st));
+    TRY(cast_batch_add(cb, lp[L_FC2W], lw + w.fc2, (long long)d.D * d.M, st));
+  }
+  TRY(cast_batch_flush(cb, st));
+  for (int i = 0; i < d.L; ++i) {
+    const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
+    bf16_t* lw = wpack + w.layer0 + w.layer_elems * i;
     if (!with_transposes) continue;
     TRY(transpose_cast_f32_bf16(lp[L_QKV], lw + w.qkvT, 3 * d.I, d.D, st));   // (3I, D) -> (D, 3I)
     TRY(transpose_cast_f32_bf16(lp[L_OUTW], lw + w.outT, d.D, d.I, st));      // (D, I)  -> (I, D)

@@ -12,6 +12,27 @@ __global__ void __launch_bounds__(256) cast_f32_bf16_kernel(const float* __restr
   reinterpret_cast<bf16x4*>(dst)[i] = __builtin_convertvector(v, bf16x4);
 }
 
+// several casts in one launch (the weight arena: 4 matrices per layer + the patch embedding; one launch per matrix was 49 launches of
+// ~5 us for the 0.1 ms of HBM time the 12-layer pack takes).  A block converts 1024 consecutive float4 of ONE segment: blocks are
+// dealt to the segments through the prefix table.
+__global__ void __launch_bounds__(256) cast_f32_bf16_batch_kernel(const CastBatch b) {
+  int lo = 0, hi = b.nseg;      // last segment whose first block is <= blockIdx.x
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((unsigned)b.first_block[mid] <= blockIdx.x) lo = mid; else hi = mid;
+  }
+  const long long n4 = b.n4[lo];
+  const fx4* __restrict__ src = reinterpret_cast<const fx4*>(b.src[lo]);
+  bf16x4* __restrict__ dst = reinterpret_cast<bf16x4*>(b.dst[lo]);
+  const long long base = (long long)(blockIdx.x - (unsigned)b.first_block[lo]) * 1024 + threadIdx.x;
+  fx4 v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = base + 256 * j < n4 ? src[base + 256 * j] : fx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (base + 256 * j < n4) dst[base + 256 * j] = __builtin_convertvector(v[j], bf16x4);
+}
+
 // 'b (h p1) (w p2) -> b (h w) (p1 p2)' (GoalFormer.py:138) with the cast to bf16 fused
 __global__ void __launch_bounds__(256) patchify_bf16_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B, int Hi,
                                                             int Wi, int ph, int pw) {
@@ -112,6 +133,30 @@ int cast_f32_bf16(const float* src, bf16_t* dst, long long n, hipStream_t st) {
   const long long n4 = n / 4;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, src, dst, n4);
   DGVIT_CHECK_LAUNCH("cast_f32_bf16");
+  return DGVIT_OK;
+}
+
+void cast_batch_init(CastBatch& b) { b.nseg = 0; b.first_block[0] = 0; }
+
+int cast_batch_add(CastBatch& b, const float* src, bf16_t* dst, long long n, hipStream_t st) {
+  DGVIT_CHECK_ARG(src && dst && n > 0 && n % 4 == 0, "cast_f32_bf16: n must be a positive multiple of 4");
+  if (b.nseg == DGVIT_CAST_SEGMENTS) {
+    const int rc = cast_batch_flush(b, st);
+    if (rc != DGVIT_OK) return rc;
+  }
+  const long long n4 = n / 4, blocks = (n4 + 1023) / 1024;
+  DGVIT_CHECK_ARG(b.first_block[b.nseg] + blocks < (1ll << 31), "cast_f32_bf16: too many elements in one batch");
+  b.src[b.nseg] = src; b.dst[b.nseg] = dst; b.n4[b.nseg] = n4;
+  b.first_block[b.nseg + 1] = b.first_block[b.nseg] + (int)blocks;
+  ++b.nseg;
+  return DGVIT_OK;
+}
+
+int cast_batch_flush(CastBatch& b, hipStream_t st) {
+  if (b.nseg == 0) return DGVIT_OK;
+  hipLaunchKernelGGL(cast_f32_bf16_batch_kernel, dim3((unsigned)b.first_block[b.nseg]), dim3(256), 0, st, b);
+  DGVIT_CHECK_LAUNCH("cast_f32_bf16_batch");
+  cast_batch_init(b);
   return DGVIT_OK;
 }
 

@@ -265,6 +265,31 @@ def test_encoder_bf16_dtype_switch():
     assert 0 < float((f32 - fbf).abs().max()) < 3e-2
 
 
+def test_weight_pack_batches_more_segments_than_one_table_holds():
+    """depth 17 = 69 fp32 -> bf16 cast segments: the batched cast (64 segments per launch) flushes once on the way; a segment that was
+    dropped would leave a weight matrix of the last layers unconverted (arena memory) and the features far off the fp32 path's"""
+    import dgvit_amd
+    torch.manual_seed(3)
+    m = dgvit_amd.GoT(image_size=(32, 32), patch_size=(8, 8), num_classes=2, dim=64, depth=17, heads=2, mlp_dim=64, channels=1).cuda().eval()
+    img, goal = torch.rand(3, 32, 32).cuda(), torch.rand(3, 64).cuda()
+    with torch.no_grad():
+        f32 = m(img, goal)
+        m.set_compute_dtype(torch.bfloat16)
+        m._bf16_weights.arena = None
+        poison = torch.full((1 << 22,), float("nan"), dtype=torch.bfloat16, device="cuda")     # the arena is carved from freed memory
+        del poison
+        fbf = m(img, goal)
+        arena = m._bf16_weights.arena
+    assert torch.isfinite(fbf).all() and float((f32 - fbf).abs().max()) < 6e-2
+    # every straight copy of the last layer is the bf16 rounding of its master (the transposes are skipped under no_grad)
+    last = m.transformer.layers[-1]
+    flat = arena.float()
+    for w in (last[0].fn.to_qkv.weight, last[0].fn.to_out[0].weight, last[1].fn.net[0].weight, last[1].fn.net[3].weight):
+        want = w.detach().to(torch.bfloat16).float().reshape(-1)
+        hits = (flat[: flat.numel() - want.numel() + 1][:: 4] == want[0]).nonzero().reshape(-1) * 4
+        assert any(torch.equal(flat[o:o + want.numel()], want) for o in hits.tolist()), tuple(w.shape)
+
+
 # ---------------------------------------------------------------------------------------------- backward
 @pytest.mark.parametrize("T,Mo,Ko", [(394, 136, 264), (4000, 768, 2304), (9001, 256, 256), (64, 8, 8), (20000, 3072, 768), (33, 520, 264),
                                      (1, 256, 256)])
