@@ -20,10 +20,11 @@ import os
 import sys
 import time
 
-# The HIP runtime multiplexes streams onto 4 hardware queues by default; with RCCL initialised, the stream the collectives run on then
-# shares a queue with the compute stream and an all-reduce queued behind a gradient-ready event still executes after the whole backward
-# (measured: tools/overlap_queue_probe.py, profiles/r03_*_overlap_*).  Must be set before the first HIP call of the process.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# --grad-overlap: the HIP runtime multiplexes streams onto 4 hardware queues by default; with RCCL initialised, the stream the collectives
+# run on then shares a queue with the compute stream and an all-reduce queued behind a gradient-ready event still executes after the whole
+# backward (measured: tools/overlap_queue_probe.py, profiles/r03_d_overlap_queue_probe.txt).  Must be set before the first HIP call.
+if "--grad-overlap" in sys.argv:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 
@@ -53,8 +54,10 @@ def parse():
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal of the N > 1 path on one GPU: initialise the RCCL process group even for one rank and run the "
                          "gradient all-reduce (a one-rank all-reduce is the identity) inside every step")
-    ap.add_argument("--no-grad-overlap", action="store_true",
-                    help="A/B: exchange all gradients after the backward instead of block by block from inside it")
+    ap.add_argument("--grad-overlap", action="store_true",
+                    help="start every transformer block's gradient all-reduce from inside the backward, behind its gradient-ready event "
+                         "(GradSync(overlap=True)); default: one exchange after the backward -- the overlapped form is covered by tests and a "
+                         "one-card timeline only, it has never run across real GPUs (DESIGN section 6)")
     return ap.parse_args()
 
 
@@ -305,7 +308,7 @@ def main():
     model = dgvit_amd.GoTPolicy(2, 2, DEPTH, HEADS, DIM, image_size=IMAGE, patch_size=PATCH).to(dev).train()
     model.trans.set_schedule(dense_last_block=args.dense_last_block, wgrad_overlap=args.wgrad_overlap)   # per-module options (dgvit_config.flags)
     # several ranks: every transformer block's all-reduce starts from inside the backward, behind its gradient-ready event
-    sync = GradSync([model], force_collective=args.force_collective, overlap=not args.no_grad_overlap)
+    sync = GradSync([model], force_collective=args.force_collective, overlap=args.grad_overlap)
     sync.broadcast_parameters(0)
     from dgvit_amd.optim import FlatAdam
     opt = FlatAdam([model], lr=1e-4)            # torch.optim.Adam semantics, one HIP kernel per flat block
@@ -430,7 +433,7 @@ def main():
                        "last_block": "dense" if args.dense_last_block else "token-0 rows only (identical results; FLOPs counted dense)",
                        "wgrad_overlap": bool(args.wgrad_overlap),
                        "grad_allreduce": ("none (one rank)" if not (world > 1 or args.force_collective) else
-                                          "after the backward" if args.no_grad_overlap else
+                                          "after the backward" if not args.grad_overlap else
                                           f"per transformer block from inside the backward ({sync.early_launches // max(1, args.steps + args.warmup)} early all-reduces per step), rest after it")},
             "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
