@@ -179,8 +179,11 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_fwd_kernel(const float* __res
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
       }
+      // (a step contracts keys acc_row(r, 0) and + 4 of the tile; past N both probabilities are exact zeros: the step is skipped,
+      //  wave-uniformly -- at N = 50, 6 of the second tile's 16 steps)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        if (kt * 32 + acc_row(r, 0) >= N) continue;
         const float* vrow = Vs + (kt * 32 + acc_row(r, h)) * SK + li;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[dt * 32], s0[r], o[dt], 0, 0, 0);
@@ -188,6 +191,7 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_fwd_kernel(const float* __res
       if (two) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          if ((kt + 1) * 32 + acc_row(r, 0) >= N) continue;
           const float* vrow = Vs + ((kt + 1) * 32 + acc_row(r, h)) * SK + li;
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[dt * 32], s1[r], o[dt], 0, 0, 0);
@@ -424,6 +428,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd64_kernel(const float* __restr
     zero_tiles<DT>(dq);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      if (kt * 32 + acc_row(r, 0) >= N) continue;     // both keys of the step are padding (dS = 0): wave-uniform skip
       const float* krow = X + (kt * 32 + acc_row(r, h)) * SK + li;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[dt * 32], sT[r], dq[dt], 0, 0, 0);
@@ -475,6 +480,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd64_kernel(const float* __restr
       const float pe[4] = {pf.x, pf.y, pf.z, pf.w}, se[4] = {sf.x, sf.y, sf.z, sf.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        if (qt * 32 + 8 * g + e >= N) continue;       // both queries of the step are padding (dO = 0, dS = 0): wave-uniform skip
         const int q = qt * 32 + 8 * g + 4 * h + e;
         const float* dorow = Y + q * SK + li;
         const float* qrow = X + q * SK + li;

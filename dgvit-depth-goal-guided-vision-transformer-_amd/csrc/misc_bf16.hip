@@ -12,6 +12,23 @@ __global__ void __launch_bounds__(256) cast_f32_bf16_kernel(const float* __restr
   reinterpret_cast<bf16x4*>(dst)[i] = __builtin_convertvector(v, bf16x4);
 }
 
+// the same for patch widths that are multiples of 4: a thread moves four consecutive pixels of one patch row (16-byte load, 8-byte
+// store; the one-pixel form ran at 1.5 TB/s on 224 x 224 frames).  idx4 walks the OUTPUT in units of four elements.
+__global__ void __launch_bounds__(256) patchify_bf16_x4_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B, int Hi,
+                                                               int Wi, int ph, int pw) {
+  const int gw = Wi / pw, gh = Hi / ph, pd4 = ph * pw / 4, pw4 = pw / 4;
+  const long long total4 = (long long)B * gh * gw * pd4;
+  const long long idx4 = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx4 >= total4) return;
+  const int e4 = (int)(idx4 % pd4);
+  const long long bp = idx4 / pd4;
+  const int p = (int)(bp % (gh * gw));
+  const long long b = bp / (gh * gw);
+  const int p1 = e4 / pw4, q = e4 % pw4, hy = p / gw, wx = p % gw;
+  const fx4 v = *reinterpret_cast<const fx4*>(img + (b * Hi + hy * ph + p1) * Wi + wx * pw + 4 * q);
+  reinterpret_cast<bf16x4*>(out)[idx4] = __builtin_convertvector(v, bf16x4);
+}
+
 // several casts in one launch (the weight arena: 4 matrices per layer + the patch embedding; one launch per matrix was 49 launches of
 // ~5 us for the 0.1 ms of HBM time the 12-layer pack takes).  A block converts 1024 consecutive float4 of ONE segment: blocks are
 // dealt to the segments through the prefix table.
@@ -164,6 +181,11 @@ int patchify_bf16(const float* img, bf16_t* out, int B, int Hi, int Wi, int ph, 
   DGVIT_CHECK_ARG(img && out && B > 0, "patchify_bf16: bad arguments");
   DGVIT_CHECK_ARG(ph > 0 && pw > 0 && Hi % ph == 0 && Wi % pw == 0, "Image dimensions must be divisible by the patch size.");
   const long long total = (long long)B * Hi * Wi;
+  if (pw % 4 == 0 && Wi % 4 == 0 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)out & 7) == 0) {   // four pixels of a patch row per thread
+    hipLaunchKernelGGL(patchify_bf16_x4_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, img, out, B, Hi, Wi, ph, pw);
+    DGVIT_CHECK_LAUNCH("patchify_bf16");
+    return DGVIT_OK;
+  }
   hipLaunchKernelGGL(patchify_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, out, B, Hi, Wi, ph, pw);
   DGVIT_CHECK_LAUNCH("patchify_bf16");
   return DGVIT_OK;

@@ -29,3 +29,14 @@ if os.environ.get("TIME", "1") == "1":
     for rnd in range(3):
         print(f"round {rnd}: two-phase {t(0):.1f} us   single-pass {t(1):.1f} us", flush=True)
     lib.dgvit_set_attention_bwd_single_pass(1)
+    def tf(reps=50):
+        for _ in range(5):
+            F.op_attention_fwd(qkv, H, dh)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            F.op_attention_fwd(qkv, H, dh)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e3
+    print(f"forward {tf():.1f} us  {tf():.1f} us", flush=True)
