@@ -367,15 +367,16 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_bwd_kernel(const float* __res
 // 160 MFMAs per pair instead of 224, no second fetch of K / V fragments, no lse / delta arrays; 70 KB of LDS (2 workgroups per CU,
 // 8 waves, as before) and a third of the per-wave dependent MFMA chain.
 template <int DH>
-__global__ void __launch_bounds__(256, 2) attn_bwd64_kernel(const float* __restrict__ qkv, const float* __restrict__ o_fwd,
+__global__ void __launch_bounds__(256, 3) attn_bwd64_kernel(const float* __restrict__ qkv, const float* __restrict__ o_fwd,
                                                             const float* __restrict__ d_out, const float* __restrict__ lse,
                                                             float* __restrict__ dqkv, int N, int H, float scale) {
   constexpr int SK = DH + 4, DT = DH / 32, NP = 64, TQ = NP + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* X = smem;                 // step 1: K      step 3: Q
+  float* X = smem;                 // step 1: K      step 3: Q          (step 4: dV partial [key][d])
   float* Y = X + NP * SK;          // step 1: V      step 3: dO
-  float* TP = Y + NP * SK;         // P^T  [key][query]        (step 4: dK partial [key][d])
-  float* TS = TP + NP * TQ;        // dS^T [key][query]        (step 4: dV partial [key][d])
+  float* T = Y + NP * SK;          // [key][query] image: P^T for dV, then dS^T for dK   (step 4: dK partial [key][d])
+  // (ONE [key][query] image, used twice -- P^T, then dS^T written from the registers that kept it -- instead of two: 52 KB of LDS
+  //  per workgroup instead of 70, three workgroups per CU instead of two; the kernel is bound by latency, not by its matrix work)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int b = blockIdx.x / H, hd = blockIdx.x % H;
@@ -386,10 +387,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd64_kernel(const float* __restr
   const float* dobase = d_out + (long long)b * N * I + hd * DH;
   float* gbase = dqkv + (long long)b * N * ld + hd * DH;
   const float qscale = scale * DGVIT_LOG2E;
-  // ---- step 1: wave (qt, kt)
+  f32x16 dsT;                      // dS^T tile of this wave's (query tile, key tile) pair, kept from step 1 to step 3b
+  const int qt1 = wave & 1, kt1 = wave >> 1, q1 = qt1 * 32 + li;
+  // ---- step 1: wave (qt1, kt1)
   {
-    const int qt = wave & 1, kt = wave >> 1;
-    const int q = qt * 32 + li;
+    const int qt = qt1, kt = kt1, q = q1;
     const bool qv = q < N;
     const int qc = qv ? q : 0;
     float4 qf[DH / 8], dof[DH / 8];
@@ -419,10 +421,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd64_kernel(const float* __restr
     for (int r = 0; r < 16; ++r) {
       const int key = kt * 32 + acc_row(r, h);
       const float pv = key < N ? __builtin_amdgcn_exp2f(sT[r] - lq) : 0.f;
-      const float ds = pv * (dpT[r] - delta) * scale;
-      TP[key * TQ + q] = pv;         // consecutive lanes -> consecutive queries: conflict-free
-      TS[key * TQ + q] = ds;
-      sT[r] = ds;
+      T[key * TQ + q] = pv;          // consecutive lanes -> consecutive queries: conflict-free
+      dsT[r] = pv * (dpT[r] - delta) * scale;
     }
     f32x16 dq[DT];
     zero_tiles<DT>(dq);
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd64_kernel(const float* __restr
       if (kt * 32 + acc_row(r, 0) >= N) continue;     // both keys of the step are padding (dS = 0): wave-uniform skip
       const float* krow = X + (kt * 32 + acc_row(r, h)) * SK + li;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[dt * 32], sT[r], dq[dt], 0, 0, 0);
+      for (int dt = 0; dt < DT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[dt * 32], dsT[r], dq[dt], 0, 0, 0);
     }
     __syncthreads();                 // every wave is done with the K / V images
     // ---- step 2: dQ = partial(kt = 0) + partial(kt = 1), through the (now free) X image, rows = queries
@@ -466,7 +466,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd64_kernel(const float* __restr
     }
     __syncthreads();
   }
-  // ---- step 3: wave (kt, qt), key on the lane
+  // ---- step 3: wave (kt, qt), key on the lane.  3a: dV^T += dO^T P from the P^T image; then the image is rewritten with dS^T
+  // (each wave its step-1 tile) for 3b: dK^T += Q^T dS
   {
     const int kt = wave & 1, qt = wave >> 1;
     const int key = kt * 32 + li;
@@ -475,26 +476,36 @@ __global__ void __launch_bounds__(256, 2) attn_bwd64_kernel(const float* __restr
     zero_tiles<DT>(dv);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4 pf = *reinterpret_cast<const float4*>(TP + key * TQ + qt * 32 + 8 * g + 4 * h);
-      const float4 sf = *reinterpret_cast<const float4*>(TS + key * TQ + qt * 32 + 8 * g + 4 * h);
-      const float pe[4] = {pf.x, pf.y, pf.z, pf.w}, se[4] = {sf.x, sf.y, sf.z, sf.w};
+      const float4 pf = *reinterpret_cast<const float4*>(T + key * TQ + qt * 32 + 8 * g + 4 * h);
+      const float pe[4] = {pf.x, pf.y, pf.z, pf.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (qt * 32 + 8 * g + e >= N) continue;       // both queries of the step are padding (dO = 0, dS = 0): wave-uniform skip
-        const int q = qt * 32 + 8 * g + 4 * h + e;
-        const float* dorow = Y + q * SK + li;
-        const float* qrow = X + q * SK + li;
+        if (qt * 32 + 8 * g + e >= N) continue;       // both queries of the step are padding (dO = 0): wave-uniform skip
+        const float* dorow = Y + (qt * 32 + 8 * g + 4 * h + e) * SK + li;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow[dt * 32], pe[e], dv[dt], 0, 0, 0);
-          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[dt * 32], se[e], dk[dt], 0, 0, 0);
-        }
+        for (int dt = 0; dt < DT; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow[dt * 32], pe[e], dv[dt], 0, 0, 0);
       }
     }
-    __syncthreads();                 // the [key][query] images have been consumed
-    // ---- step 4: dK / dV = partial(qt = 0) + partial(qt = 1), through the TP / TS regions, rows = keys
-    float* ek = TP + key * TQ;
-    float* ev = TS + key * TQ;
+    __syncthreads();                 // P^T has been consumed
+#pragma unroll
+    for (int r = 0; r < 16; ++r) T[(kt1 * 32 + acc_row(r, h)) * TQ + q1] = dsT[r];
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 sf = *reinterpret_cast<const float4*>(T + key * TQ + qt * 32 + 8 * g + 4 * h);
+      const float se[4] = {sf.x, sf.y, sf.z, sf.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (qt * 32 + 8 * g + e >= N) continue;       // (dS = 0)
+        const float* qrow = X + (qt * 32 + 8 * g + 4 * h + e) * SK + li;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[dt * 32], se[e], dk[dt], 0, 0, 0);
+      }
+    }
+    __syncthreads();                 // the dS^T image and the Q / dO images have been consumed
+    // ---- step 4: dK / dV = partial(qt = 0) + partial(qt = 1), through the T / X regions, rows = keys
+    float* ek = T + key * TQ;
+    float* ev = X + key * SK;
     if (qt == 1) {
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
@@ -527,7 +538,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd64_kernel(const float* __restr
 template <int DH>
 int launch_bwd64(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, int B, int N, int H, float scale,
                  hipStream_t stream) {
-  constexpr size_t lds = (size_t)(2 * 64 * (DH + 4) + 2 * 64 * 68) * sizeof(float);
+  constexpr size_t lds = (size_t)(2 * 64 * (DH + 4) + 64 * 68) * sizeof(float);   // 52 KB at dim_head 64: three workgroups per CU
   auto kern = attn_bwd64_kernel<DH>;
   static DeviceOnce once;
   if (const unsigned long long bit = once.pending()) {
