@@ -13,8 +13,14 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 440
 lib = dgvit_amd.diagnostic_library().__enter__()
 T = B * 197
 g = torch.Generator(device="cuda").manual_seed(0)
-ARMS = [("stream (warm-up)", 256257, 0), ("stream", 256257, 0), ("non-temporal stores", 256257, 2048), ("hot source", 256257, 1), ("hot source, nt stores", 256257, 2049),
-        ("stream again", 256257, 0), ("non-temporal stores again", 256257, 2048), ("nt stores + priority", 256257, 3072)]
+# timing variants of gemm_bf16_stream_kernel (csrc/gemm_bf16_stream.hip, SDIAG bits): 1 cache-hot source, 2 no DMA, 4 no fragment reads,
+# 8 no epilogue, 16 no barrier, 32 no MFMA, 64 accumulators kept alive without an epilogue, 128 DMA amid the MFMAs, 256 SIMD partners
+# lead / trail, 512 per-wave stamps (tools/bf16_stream_stamps.py), 1024 waves 4-7 at priority 1, 2048 ORDINARY output stores (the
+# shipped kernel's are non-temporal)
+ARMS = [("stream (warm-up)", 256257, 0), ("ring (old)", 256256, 0), ("stream", 256257, 0), ("ordinary (temporal) stores", 256257, 2048),
+        ("hot source", 256257, 1), ("main loop only (no epilogue)", 256257, 72), ("main loop, hot source", 256257, 73),
+        ("main loop, no dma", 256257, 74), ("no MFMA, no epilogue", 256257, 40), ("DMA amid MFMAs", 256257, 128),
+        ("SIMD partners: lead / trail", 256257, 256), ("waves 4-7 at priority 1", 256257, 1024), ("stream again", 256257, 0)]
 
 
 def timeit(fn, iters=20, warm=3):
