@@ -73,6 +73,17 @@ __device__ __forceinline__ void sched_half() {
     __builtin_amdgcn_sched_group_barrier(0x10, 4, 0);
     return;
   }
+  if (VAR == 5) {          // every fragment read of the half up front, the DMAs later, among matrix instructions only
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
+    return;
+  }
   if (VAR == 4) {          // its partner: DMAs and fragment reads first, matrix work behind them
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -105,7 +116,7 @@ __device__ __forceinline__ void sched_half() {
 
 template <int EPI, int DIAG, int ROLE>     // ROLE: 0 every wave the same schedule; 1 / 2 leading / trailing wave of a SIMD pair (timing variant 256)
 __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles) {
-  constexpr int HVAR = ROLE == 1 ? 3 : ROLE == 2 ? 4 : SDIAG(128) ? 1 : 0;
+  constexpr int HVAR = ROLE == 1 ? 3 : ROLE == 2 ? 4 : SDIAG(4096) ? 5 : SDIAG(128) ? 1 : 0;
   constexpr bool OUT_F32 = EPI == BEPI_F32_PLAIN;
   // Output stores are non-temporal (aux bit 1): C is never read again by this launch and is larger than the L2s, so letting it allocate there
   // only evicts the A / B k-slices that the neighbouring tiles are about to re-read (measured at B = 440: QKV 313 -> 278 us, fc1 420 -> 394 us,
@@ -157,12 +168,12 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
   auto dma_a = [&](int i) {
     if constexpr (!SDIAG(2))
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(smem + lslot * PIECE + wave * 1024 + i * 8192), 16,
-                                               ((offA + (SDIAG(1) ? 0u : (unsigned)lt * 128u)) | ldead) + i * stepA, 0, 0, 0);
+                                               ((offA + (SDIAG(1) ? 0u : (unsigned)lt * 128u)) | ldead) + i * stepA, 0, 0, SDIAG(8192) ? 2 : 0);
   };
   auto dma_b = [&](int i) {
     if constexpr (!SDIAG(2))
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(smem + lslot * PIECE + wave * 1024 + i * 8192), 16,
-                                               ((offB + (SDIAG(1) ? 0u : (unsigned)lt * 128u)) | ldead) + i * stepB, 0, 0, 0);
+                                               ((offB + (SDIAG(1) ? 0u : (unsigned)lt * 128u)) | ldead) + i * stepB, 0, 0, SDIAG(16384) ? 2 : 0);
   };
   auto next_slot = [&]() { lslot = lslot + 1 == NSLOT ? 0 : lslot + 1; };
   auto next_ktile = [&]() {     // after the B piece
@@ -532,7 +543,7 @@ int gemm_bf16_stream(int epi, const GemmBf16Params& p, hipStream_t st) {
   if (g_gemm_diag && (epi == BEPI_BF16 || epi == BEPI_GELU_BF16)) {
 #define DGVIT_SD(D)                                                                        \
   if (g_gemm_diag == D) return epi == BEPI_BF16 ? launch_stream<BEPI_BF16, D>(p, st) : launch_stream<BEPI_GELU_BF16, D>(p, st);
-    DGVIT_SD(1) DGVIT_SD(2) DGVIT_SD(4) DGVIT_SD(8) DGVIT_SD(10) DGVIT_SD(14) DGVIT_SD(18) DGVIT_SD(30) DGVIT_SD(32) DGVIT_SD(40) DGVIT_SD(41) DGVIT_SD(44) DGVIT_SD(16) DGVIT_SD(72) DGVIT_SD(73) DGVIT_SD(74) DGVIT_SD(76) DGVIT_SD(88) DGVIT_SD(128) DGVIT_SD(256) DGVIT_SD(512) DGVIT_SD(768) DGVIT_SD(1024) DGVIT_SD(1536) DGVIT_SD(1280) DGVIT_SD(2048) DGVIT_SD(2049) DGVIT_SD(3072)
+    DGVIT_SD(1) DGVIT_SD(2) DGVIT_SD(4) DGVIT_SD(8) DGVIT_SD(10) DGVIT_SD(14) DGVIT_SD(18) DGVIT_SD(30) DGVIT_SD(32) DGVIT_SD(40) DGVIT_SD(41) DGVIT_SD(44) DGVIT_SD(16) DGVIT_SD(72) DGVIT_SD(73) DGVIT_SD(74) DGVIT_SD(76) DGVIT_SD(88) DGVIT_SD(128) DGVIT_SD(256) DGVIT_SD(512) DGVIT_SD(768) DGVIT_SD(1024) DGVIT_SD(1536) DGVIT_SD(1280) DGVIT_SD(2048) DGVIT_SD(2049) DGVIT_SD(3072) DGVIT_SD(4096) DGVIT_SD(4168) DGVIT_SD(8192) DGVIT_SD(16384) DGVIT_SD(24576)
 #undef DGVIT_SD
     return dgvit_set_error(DGVIT_ERR_ARG, "gemm_bf16_stream: no timing variant %d", g_gemm_diag);
   }

@@ -17,10 +17,8 @@ g = torch.Generator(device="cuda").manual_seed(0)
 # 8 no epilogue, 16 no barrier, 32 no MFMA, 64 accumulators kept alive without an epilogue, 128 DMA amid the MFMAs, 256 SIMD partners
 # lead / trail, 512 per-wave stamps (tools/bf16_stream_stamps.py), 1024 waves 4-7 at priority 1, 2048 ORDINARY output stores (the
 # shipped kernel's are non-temporal)
-ARMS = [("stream (warm-up)", 256257, 0), ("ring (old)", 256256, 0), ("stream", 256257, 0), ("ordinary (temporal) stores", 256257, 2048),
-        ("hot source", 256257, 1), ("main loop only (no epilogue)", 256257, 72), ("main loop, hot source", 256257, 73),
-        ("main loop, no dma", 256257, 74), ("no MFMA, no epilogue", 256257, 40), ("DMA amid MFMAs", 256257, 128),
-        ("SIMD partners: lead / trail", 256257, 256), ("waves 4-7 at priority 1", 256257, 1024), ("stream again", 256257, 0)]
+ARMS = [("stream (warm-up)", 256257, 0), ("stream", 256257, 0), ("A loads non-temporal", 256257, 8192), ("B loads non-temporal", 256257, 16384),
+        ("A and B loads non-temporal", 256257, 24576), ("stream again", 256257, 0), ("A nt again", 256257, 8192), ("B nt again", 256257, 16384)]
 
 
 def timeit(fn, iters=20, warm=3):
