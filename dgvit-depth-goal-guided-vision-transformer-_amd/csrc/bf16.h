@@ -83,6 +83,8 @@ int layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, bf
                        float eps, int rs, hipStream_t st);
 int add_layernorm_fwd_bf16(const float* x, const bf16_t* delta, float* xout, const float* gamma, const float* beta, bf16_t* y,
                            float* mean, float* rstd, int T, int D, float eps, int rs, hipStream_t st);
+int add2_layernorm_fwd_bf16(const float* x, const bf16_t* delta, const bf16_t* delta2, float* xout, const float* gamma, const float* beta,
+                            bf16_t* y, int T, int D, float eps, hipStream_t st);
 int residual_add_bf16(const float* x, const bf16_t* delta, float* xout, int rows, int D, int rs, hipStream_t st);
 int layernorm_bwd_bf16(const bf16_t* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
                        float* dx, bf16_t* dxb, float* dgamma, float* dbeta, float* partial, int T, int D, int rs, hipStream_t st);

@@ -1259,8 +1259,14 @@ extern "C" int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* cons
       p.bias = lp[L_OUTB];
       TRY(gemm_bf16(BEPI_BF16, p, st));
     }
-    // xmid = x + to_out(..);  ln2 = LN2(xmid)
-    TRY(add_layernorm_fwd_bf16(x, delta, xmid, lp[L_LN2W], lp[L_LN2B], ln2, f32(lb, w.mean2), f32(lb, w.rstd2), tok, d.D, 1e-5f, rs, st));
+    // xmid = x + to_out(..);  ln2 = LN2(xmid).  No-grad passes do not store xmid in the blocks that have a successor: the feed-forward
+    // output goes to the (free again) attention-output buffer and both branch outputs join the stream in ONE pass below,
+    // (x + d_attn) + d_ff in the order of the two-step schedule: identical results, 22 instead of 24 bytes per element and block
+    const bool joint = !save && i + 1 < d.L && d.I >= d.D;     // (the attention-output buffer holds T x I elements)
+    if (joint)
+      TRY(add2_layernorm_fwd_bf16(x, delta, nullptr, nullptr, lp[L_LN2W], lp[L_LN2B], ln2, T, d.D, 1e-5f, st));
+    else
+      TRY(add_layernorm_fwd_bf16(x, delta, xmid, lp[L_LN2W], lp[L_LN2B], ln2, f32(lb, w.mean2), f32(lb, w.rstd2), tok, d.D, 1e-5f, rs, st));
     {
       GemmBf16Params p = gpb(ln2, rs * d.D, lw + wp.fc1, d.D, a1, d.M, tok, d.M, d.D);
       p.bias = lp[L_FC1B];
@@ -1272,12 +1278,16 @@ extern "C" int dgvit_got_forward_bf16(const dgvit_config* cfg, const float* cons
       }
     }
     {
-      GemmBf16Params p = gpb(a1, d.M, lw + wp.fc2, d.M, delta, rs * d.D, tok, d.D, d.M);
+      GemmBf16Params p = gpb(a1, d.M, lw + wp.fc2, d.M, joint ? ao : delta, rs * d.D, tok, d.D, d.M);
       p.bias = lp[L_FC2B];
       TRY(gemm_bf16(BEPI_BF16, p, st));
     }
     // xo = xmid + ff(..), and the next block's LN1 of it
-    if (i + 1 < d.L) {
+    if (joint) {
+      unsigned char* nb = ws + w.layer0 + w.layer_stride * (i + 1);
+      TRY(add2_layernorm_fwd_bf16(x, delta, ao, xo, lp[DGVIT_PARAMS_PER_LAYER + L_LN1W], lp[DGVIT_PARAMS_PER_LAYER + L_LN1B],
+                                  (bf16_t*)(nb + w.ln), T, d.D, 1e-5f, st));
+    } else if (i + 1 < d.L) {
       unsigned char* nb = ws + w.layer0 + w.layer_stride * (i + 1);
       TRY(add_layernorm_fwd_bf16(xmid, delta, xo, lp[DGVIT_PARAMS_PER_LAYER + L_LN1W], lp[DGVIT_PARAMS_PER_LAYER + L_LN1B],
                                  (bf16_t*)(nb + w.ln), f32(nb, w.mean1), f32(nb, w.rstd1), T, d.D, 1e-5f, 1, st));

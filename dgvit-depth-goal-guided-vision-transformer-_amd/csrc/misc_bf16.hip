@@ -68,10 +68,13 @@ __global__ void __launch_bounds__(256) patchify_bf16_kernel(const float* __restr
 
 // nn.LayerNorm(D), eps 1e-5 (GoalFormer.py:34,37): fp32 row in, bf16 row out; one wave per row, row kept in registers.
 // ADD: the row is first completed with the bf16 branch output of the previous sub-block (GoalFormer.py:103-104:
-// x = attn(..) + x / x = ff(..) + x): v = x + delta, written back to the fp32 residual stream `xout`.
+// x = attn(..) + x / x = ff(..) + x): v = x + delta, written back to the fp32 residual stream `xout` (unless NULL).  With `delta2`
+// both branch outputs of a block join at once: v = (x + delta) + delta2 -- the no-grad forward does not store the stream between
+// the attention and the feed-forward branch (22 instead of 24 bytes per element and block).
 template <int NCH, bool ADD>
 __global__ void __launch_bounds__(256) layernorm_fwd_bf16_kernel(const float* __restrict__ x, const bf16_t* __restrict__ delta,
-                                                                 float* __restrict__ xout, const float* __restrict__ gamma,
+                                                                 const bf16_t* __restrict__ delta2, float* __restrict__ xout,
+                                                                 const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, bf16_t* __restrict__ y,
                                                                  float* __restrict__ mean, float* __restrict__ rstd, int T, int D,
                                                                  float eps, int rs) {
@@ -88,8 +91,10 @@ __global__ void __launch_bounds__(256) layernorm_fwd_bf16_kernel(const float* __
     if (c < D) {
       v[i] = *reinterpret_cast<const fx4*>(xr + c);
       if (ADD) {
+        // (x + delta) + delta2 in this order: the sums a two-step schedule (x_mid written, then x_mid + delta2) would form
         v[i] += __builtin_convertvector(*reinterpret_cast<const bf16x4*>(delta + (long long)row * rs * D + c), fx4);
-        *reinterpret_cast<fx4*>(xout + (long long)row * rs * D + c) = v[i];
+        if (delta2) v[i] += __builtin_convertvector(*reinterpret_cast<const bf16x4*>(delta2 + (long long)row * rs * D + c), fx4);
+        if (xout) *reinterpret_cast<fx4*>(xout + (long long)row * rs * D + c) = v[i];
       }
     }
     s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -192,18 +197,18 @@ int patchify_bf16(const float* img, bf16_t* out, int B, int Hi, int Wi, int ph, 
 }
 
 template <bool ADD>
-static int layernorm_launch(const float* x, const bf16_t* delta, float* xout, const float* gamma, const float* beta, bf16_t* y,
-                            float* mean, float* rstd, int T, int D, float eps, int rs, hipStream_t st) {
+static int layernorm_launch(const float* x, const bf16_t* delta, const bf16_t* delta2, float* xout, const float* gamma, const float* beta,
+                            bf16_t* y, float* mean, float* rstd, int T, int D, float eps, int rs, hipStream_t st) {
   DGVIT_CHECK_ARG(x && gamma && beta && y && T > 0, "layernorm_bf16: bad arguments");
   DGVIT_CHECK_ARG(D > 0 && D % 4 == 0 && D <= 1024, "layernorm_bf16: D=%d must be a multiple of 4 and <= 1024", D);
   const int slot = profile_begin(PROF_OTHER, 0.0, st);
   const dim3 grid((unsigned)((T + 3) / 4)), blk(256);
   if (D <= 256)
-    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<1, ADD>), grid, blk, 0, st, x, delta, xout, gamma, beta, y, mean, rstd, T, D, eps, rs);
+    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<1, ADD>), grid, blk, 0, st, x, delta, delta2, xout, gamma, beta, y, mean, rstd, T, D, eps, rs);
   else if (D <= 512)
-    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<2, ADD>), grid, blk, 0, st, x, delta, xout, gamma, beta, y, mean, rstd, T, D, eps, rs);
+    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<2, ADD>), grid, blk, 0, st, x, delta, delta2, xout, gamma, beta, y, mean, rstd, T, D, eps, rs);
   else
-    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<4, ADD>), grid, blk, 0, st, x, delta, xout, gamma, beta, y, mean, rstd, T, D, eps, rs);
+    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<4, ADD>), grid, blk, 0, st, x, delta, delta2, xout, gamma, beta, y, mean, rstd, T, D, eps, rs);
   profile_end(slot, st);
   DGVIT_CHECK_LAUNCH("layernorm_fwd_bf16");
   return DGVIT_OK;
@@ -211,13 +216,20 @@ static int layernorm_launch(const float* x, const bf16_t* delta, float* xout, co
 
 int layernorm_fwd_bf16(const float* x, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd, int T, int D,
                        float eps, int rs, hipStream_t st) {
-  return layernorm_launch<false>(x, nullptr, nullptr, gamma, beta, y, mean, rstd, T, D, eps, rs, st);
+  return layernorm_launch<false>(x, nullptr, nullptr, nullptr, gamma, beta, y, mean, rstd, T, D, eps, rs, st);
 }
 
 int add_layernorm_fwd_bf16(const float* x, const bf16_t* delta, float* xout, const float* gamma, const float* beta, bf16_t* y,
                            float* mean, float* rstd, int T, int D, float eps, int rs, hipStream_t st) {
   DGVIT_CHECK_ARG(delta && xout, "add_layernorm_bf16: bad arguments");
-  return layernorm_launch<true>(x, delta, xout, gamma, beta, y, mean, rstd, T, D, eps, rs, st);
+  return layernorm_launch<true>(x, delta, nullptr, xout, gamma, beta, y, mean, rstd, T, D, eps, rs, st);
+}
+
+// y = LN((x + delta) + delta2), the sum written to xout unless it is NULL; delta2 may be NULL (no-grad forward, dgvit_api.hip)
+int add2_layernorm_fwd_bf16(const float* x, const bf16_t* delta, const bf16_t* delta2, float* xout, const float* gamma, const float* beta,
+                            bf16_t* y, int T, int D, float eps, hipStream_t st) {
+  DGVIT_CHECK_ARG(delta, "add2_layernorm_bf16: bad arguments");
+  return layernorm_launch<true>(x, delta, delta2, xout, gamma, beta, y, nullptr, nullptr, T, D, eps, 1, st);
 }
 
 // ---------------------------------------------------------------------------------------------- backward helpers

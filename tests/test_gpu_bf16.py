@@ -265,6 +265,22 @@ def test_encoder_bf16_dtype_switch():
     assert 0 < float((f32 - fbf).abs().max()) < 3e-2
 
 
+@pytest.mark.parametrize("dim,heads", [(64, 2), (128, 1)], ids=["inner>=dim", "inner<dim"])
+def test_no_grad_forward_equals_the_saving_forward_bitwise(dim, heads):
+    """the no-grad bf16 forward joins both branch outputs of a block with the residual stream in one pass ((x + d_attn) + d_ff, the
+    intermediate stream never stored; only when the attention-output buffer can hold the feed-forward output: inner >= dim) and
+    prunes the last block to token 0; the forward that saves for backward does neither.  Same sums in the same order: equal bits."""
+    import dgvit_amd
+    torch.manual_seed(11)
+    m = dgvit_amd.GoT(image_size=(48, 48), patch_size=(8, 8), num_classes=2, dim=dim, depth=3, heads=heads, mlp_dim=128, channels=1).cuda().eval()
+    m.set_compute_dtype(torch.bfloat16)
+    img, goal = torch.rand(5, 48, 48).cuda(), torch.rand(5, dim).cuda()
+    with torch.no_grad():
+        a = m(img, goal)
+    b = m(img, goal.clone().requires_grad_(True))
+    assert b.requires_grad and torch.equal(a, b.detach())
+
+
 def test_weight_pack_batches_more_segments_than_one_table_holds():
     """depth 17 = 69 fp32 -> bf16 cast segments: the batched cast (64 segments per launch) flushes once on the way; a segment that was
     dropped would leave a weight matrix of the last layers unconverted (arena memory) and the features far off the fp32 path's"""
