@@ -690,12 +690,16 @@ int dispatch(const GemmBf16Params& p, hipStream_t st) {
   if (!tile) {
     const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     tile = (p.ksplit > 1 || p.tn || (p.M >= 256 && p.N >= 256 && t256 >= 512)) ? 256256 : 128128;
+    // a handful of 128 x 128 tiles with a long K (the token-0-only last block at inference: 440 x 768 x 3072 = 24 tiles) leaves nine CUs
+    // in ten idle behind a serial k-loop: 64 x 64 tiles give four times the workgroups
+    if (tile == 128128 && (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) < 128) tile = 64064;
     if (tile == 256256 && gemm_bf16_stream_supports(EPI, p)) tile = 256257;   // the stream kernel (gemm_bf16_stream.hip) where it applies
   }
   switch (tile) {
     case 256256: return launch<BTile<256, 256, 2, 4>, EPI, true>(p, st);
     case 256128: return launch<BTile<256, 128, 4, 2>, EPI, true>(p, st);
     case 128128: return launch<BTile<128, 128, 2, 2>, EPI, false>(p, st);
+    case 64064: return launch<BTile<64, 64, 2, 2>, EPI, false>(p, st);
     case 256257:   // (a hint for a problem the stream kernel does not take falls back to the ring kernel)
       if (!gemm_bf16_stream_supports(EPI, p)) return launch<BTile<256, 256, 2, 4>, EPI, true>(p, st);
       return gemm_bf16_stream(EPI, p, st);

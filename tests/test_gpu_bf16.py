@@ -62,7 +62,7 @@ GEMM_SHAPES = [(256, 256, 64), (512, 768, 768), (200, 136, 104), (50, 64, 256), 
                (197 * 3, 2304, 768), (1000, 768, 3072), (8200, 4104, 72), (6000, 5124, 40), (9000, 2052, 8)]
 
 
-@pytest.mark.parametrize("tile", [0, 128128, 256128, 256256, 256257])
+@pytest.mark.parametrize("tile", [0, 64064, 128128, 256128, 256256, 256257])
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
 def test_gemm_bf16_f32_out_bias_residual(F, mfma16, M, N, K, tile):
     """fp32 output = exact products of bf16 operands summed in fp32: error is accumulation only"""
@@ -72,7 +72,7 @@ def test_gemm_bf16_f32_out_bias_residual(F, mfma16, M, N, K, tile):
     close(y, a @ b.T + bias + res, atol=2e-5 * K ** 0.5 + 1e-5 * K ** 0.5 * 8, msg=f"{M}x{N}x{K} tile {tile}")
 
 
-@pytest.mark.parametrize("tile", [0, 256256, 256128, 256257])
+@pytest.mark.parametrize("tile", [0, 64064, 256256, 256128, 256257])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (200, 136, 104), (591, 2304, 768), (37, 132, 264), (5000, 1540, 72), (777, 520, 3080)])
 def test_gemm_bf16_bf16_out_and_gelu(F, mfma16, M, N, K, tile):
     with knobs(gemm_bf16_tile=tile):
