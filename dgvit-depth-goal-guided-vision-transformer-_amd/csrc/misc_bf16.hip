@@ -218,6 +218,8 @@ static int layernorm_launch(const float* x, const bf16_t* delta, const bf16_t* d
     hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<1, ADD>), grid, blk, 0, st, x, delta, delta2, xout, gamma, beta, y, mean, rstd, T, D, eps, rs);
   else if (D <= 512)
     hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<2, ADD>), grid, blk, 0, st, x, delta, delta2, xout, gamma, beta, y, mean, rstd, T, D, eps, rs);
+  else if (D <= 768)     // (ViT-Base: no dead fourth chunk in the row loops)
+    hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<3, ADD>), grid, blk, 0, st, x, delta, delta2, xout, gamma, beta, y, mean, rstd, T, D, eps, rs);
   else
     hipLaunchKernelGGL((layernorm_fwd_bf16_kernel<4, ADD>), grid, blk, 0, st, x, delta, delta2, xout, gamma, beta, y, mean, rstd, T, D, eps, rs);
   profile_end(slot, st);
