@@ -80,6 +80,26 @@ def _worker(rank, world, port, out):
         assert all(q.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for q in members)
         assert all(torch.all(q.grad == 15.0) for q in loose)
         assert sync.grad_numel() == flat.numel() + sum(q.numel() for q in loose)
+        # overlapped form, host logic only (the HIP events need a GPU: tests/test_gpu_ddp.py): two middle ranges of the flat buffer were
+        # reduced "early" (as GradSync._on_grads_ready does from inside a backward); sync() must exchange exactly the three gaps
+        # around them plus the loose tensors, wait for everything, and scale the whole buffer once
+        flat.fill_(float(rank + 1))
+        for q in loose:
+            q.grad.fill_(10.0 * (rank + 1))
+        key, n = flat.untyped_storage().data_ptr(), flat.numel()
+        a, b, c, d = n // 5, 2 * n // 5, 3 * n // 5, 4 * n // 5
+        for lo, hi in ((c, d), (a, b)):                  # last block first, as the backward finishes them
+            sync._early.append((key, lo, hi, dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)))
+        sync.sync()
+        assert torch.all(flat == 1.5) and all(torch.all(q.grad == 15.0) for q in loose) and not sync._early
+        # a reduced buffer that is not the parameters' .grad (autograd accumulated into older tensors) is refused
+        other = torch.ones(8)
+        sync._early.append((other.untyped_storage().data_ptr(), 0, 8, dist.all_reduce(other, async_op=True)))
+        try:
+            sync.sync()
+            raise AssertionError("sync() accepted an early reduction of a foreign buffer")
+        except RuntimeError as e:
+            assert "zero_grad" in str(e)
         # numpy payloads: torch tensors would travel as shared-memory handles that die with the worker
         out.put((rank, {k: (None if g is None else g.numpy().copy()) for k, g in grads.items()},
                  {k: v.numpy().copy() for k, v in state.items()}, n_live))
