@@ -205,6 +205,135 @@ __global__ void __launch_bounds__(64 * NW, 2) attn_fwd_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------ forward, 32 < N <= 64, many heads: pipelined
+// The kernel above is bound by latency, not by its matrix work (MFMA-busy 0.35-0.38 at the C3 shape): every workgroup waits for its
+// K / V / Q loads, computes, stores, and the four workgroups a CU holds drift apart only slowly.  Here a workgroup (2 waves, one per
+// query tile) walks a strided list of (frame, head) items and keeps the NEXT item's K / V rows (16 float4 per thread) and Q fragments
+// in registers while it computes the current one; after the compute they go to the same LDS images (35 KB: still four workgroups per
+// CU).  Same arithmetic, same order: bit-identical to attn_fwd_kernel<DH, 2, 2>.
+template <int DH>
+__global__ void __launch_bounds__(128, 2) attn_fwd_pipe_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                               float* __restrict__ lse, int N, int H, float scale, int items) {
+  constexpr int SK = DH + 4, DT = DH / 32, NTHR = 128, NP = 64, C4 = DH / 4, CH = NP * C4 / NTHR;   // CH = 8 float4 per image and thread
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;
+  float* Vs = smem + NP * SK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int I = H * DH;
+  const long long ld = 3ll * I;
+  const float qscale = scale * DGVIT_LOG2E;
+  const int q = wave * 32 + li;
+  const bool qv = q < N;
+
+  float4 ka[CH], va[CH], qf[DH / 8];
+  auto fetch_q = [&](int item) {    // the lane's Q fragments of `item` (pre-scaled; rows >= N zero)
+    const float* base = qkv + (long long)(item / H) * N * ld + (item % H) * DH;
+    row_frags<DH>(qf, base + (qv ? q : 0) * ld, qv, h, qscale);
+  };
+  // K / V rows of `item` -> registers, 16-byte buffer loads: one VGPR of offset (row tid / 16, columns 4 (tid % 16)), the 8-row steps and
+  // the K / V column blocks in the scalar offset; the descriptor ends with the frame's last row, so rows >= N read zeros
+  const unsigned voff = ((unsigned)(tid / C4) * (unsigned)ld + (unsigned)(tid % C4) * 4u) * 4u;
+  auto fetch = [&](int item) {
+    const int b = item / H, hd = item % H;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qkv + (long long)b * N * ld), 0, (int)(N * ld * 4), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const unsigned so = ((unsigned)(j * (NTHR / C4)) * (unsigned)ld + (unsigned)(I + hd * DH)) * 4u;
+      ka[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so, 0));
+      va[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, so + (unsigned)I * 4u, 0));
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int f = tid + j * NTHR, row = f / C4, c = (f % C4) * 4;
+      *reinterpret_cast<float4*>(Ks + row * SK + c) = ka[j];
+      *reinterpret_cast<float4*>(Vs + row * SK + c) = va[j];
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item >= items) return;
+  fetch(item);
+  fetch_q(item);
+  while (true) {
+    stash();
+    __syncthreads();                       // the images of `item` are complete
+    const int next = item + gridDim.x;
+    if (next < items) fetch(next);         // in flight during the compute below
+    // ---- both key tiles in one pass (N <= 64): no rescale step
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = 0.f;
+      s1[r] = 0.f;
+    }
+    mfma_rows_x_frags<DH, SK>(s0, Ks, li, h, qf);
+    mfma_rows_x_frags<DH, SK>(s1, Ks, 32 + li, h, qf);
+    if (next < items) fetch_q(next);       // the fragment registers are free again: the next item's arrive under the softmax and P V
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = acc_row(r, h);
+      const float v0 = key < N ? s0[r] : -INFINITY;
+      const float v1 = key + 32 < N ? s1[r] : -INFINITY;
+      s0[r] = v0;
+      s1[r] = v1;
+      mt = fmaxf(mt, fmaxf(v0, v1));
+    }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(-INFINITY, mt);                 // (the general kernel's first trip: m = -inf, alpha = 0, l = 0)
+    float ts = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p0 = __builtin_amdgcn_exp2f(s0[r] - mn), p1 = __builtin_amdgcn_exp2f(s1[r] - mn);
+      s0[r] = p0;
+      s1[r] = p1;
+      ts += p0 + p1;
+    }
+    ts += __shfl_xor(ts, 32, 64);
+    const float l = 0.f * __builtin_amdgcn_exp2f(-INFINITY - mn) + ts;
+    f32x16 o[DT];
+    zero_tiles<DT>(o);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (acc_row(r, 0) >= N) continue;
+      const float* vrow = Vs + acc_row(r, h) * SK + li;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[dt * 32], s0[r], o[dt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (32 + acc_row(r, 0) >= N) continue;
+      const float* vrow = Vs + (32 + acc_row(r, h)) * SK + li;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[dt * 32], s1[r], o[dt], 0, 0, 0);
+    }
+    if (qv) {
+      const int b = item / H, hd = item % H;
+      store_T<DH>(o, out + ((long long)b * N + q) * I + hd * DH, h, 1.f / l);
+      if (lse && h == 0) lse[((long long)b * H + hd) * N + q] = mn + __builtin_amdgcn_logf(l);
+    }
+    if (next >= items) break;
+    item = next;
+    __syncthreads();                       // every wave is done with the images before they are overwritten
+  }
+}
+
+template <int DH>
+int launch_fwd_pipe(const float* qkv, float* out, float* lse, int B, int N, int H, float scale, hipStream_t stream) {
+  constexpr size_t lds = (size_t)2 * 64 * (DH + 4) * sizeof(float);
+  const int items = B * H;
+  const int grid = items < 4 * 256 ? items : 4 * 256;      // four resident workgroups per CU
+  const int slot = profile_begin(PROF_ATTN_FWD, 4.0 * B * H * (double)N * N * DH, stream);
+  hipLaunchKernelGGL(attn_fwd_pipe_kernel<DH>, dim3(grid), dim3(128), lds, stream, qkv, out, lse, N, H, scale, items);
+  profile_end(slot, stream);
+  DGVIT_CHECK_LAUNCH("attention_fwd_pipe");
+  return DGVIT_OK;
+}
+
 // ------------------------------------------------------------------------------------ backward
 template <int DH, int NW, int NKT_CT>
 __global__ void __launch_bounds__(64 * NW, 2) attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o_fwd,
@@ -616,6 +745,10 @@ int attention_fwd(const float* qkv, float* out, float* lse, int B, int N, int H,
   DGVIT_CHECK_ARG(nq >= 1 && nq <= N, "attention_fwd: bad query count");
   DGVIT_CHECK_ARG(N <= MAX_TOKENS && (dh == 64 || dh == 32), "attention_fwd: unsupported dim_head=%d / tokens=%d (dim_head 64 or 32, N <= 224)", dh, N);
   const float scale = 1.0f / sqrtf((float)dh);
+  if (nq == N && N > 32 && N <= 64 && (long long)B * H >= 2048) {      // many short sequences: the pipelined form
+    if (dh == 64) return launch_fwd_pipe<64>(qkv, out, lse, B, N, H, scale, stream);
+    return launch_fwd_pipe<32>(qkv, out, lse, B, N, H, scale, stream);
+  }
   ATTN_DISPATCH(launch_fwd, qkv, out, lse, B, N, H, scale, nq, stream)
   return dgvit_set_error(DGVIT_ERR_ARG, "attention_fwd: no kernel for dim_head=%d", dh);
 }

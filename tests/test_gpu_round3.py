@@ -235,3 +235,24 @@ def test_capturable_state_dict_reads_the_device_step(amd):
     opt2 = FlatAdam([a], lr=1e-3, capturable=True)
     opt2.load_state_dict(sd)
     assert {s["step"] for s in opt2.state_dict()["state"] if s is not None} == {7}
+
+
+@pytest.mark.parametrize("N,H,dh", [(50, 8, 64), (37, 8, 32), (64, 4, 64), (33, 16, 64)])
+def test_pipelined_attention_forward_is_bit_identical(N, H, dh):
+    """fp32 attention forward for 32 < N <= 64 and >= 2048 (frame, head) items runs the pipelined kernel (a workgroup walks several items
+    and holds the next one's K / V / Q in registers while it computes); smaller launches run the one-item-per-workgroup kernel.  Same
+    arithmetic in the same order: the first frames of a large batch equal the same frames run as a small batch, bit for bit."""
+    import dgvit_amd
+    F = dgvit_amd.functional
+    big = (2048 + H - 1) // H + 3
+    g = torch.Generator().manual_seed(N * 100 + H)
+    qkv = torch.randn(big, N, 3 * H * dh, generator=g).cuda()
+    small = 2048 // H - 1                                   # below the threshold
+    o_big, l_big = F.op_attention_fwd(qkv, H, dh)
+    o_small, l_small = F.op_attention_fwd(qkv[:small].contiguous(), H, dh)
+    assert torch.equal(o_big[:small], o_small) and torch.equal(l_big[:small], l_small)
+    # and against fp64 arithmetic
+    I = H * dh
+    q, k, v = (qkv[-2:].double().cpu()[..., j * I:(j + 1) * I].reshape(2, N, H, dh).permute(0, 2, 1, 3) for j in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * dh ** -0.5, -1) @ v).permute(0, 2, 1, 3).reshape(2, N, I)
+    assert float((o_big[-2:].double().cpu() - ref).abs().max()) < 2e-5
