@@ -121,6 +121,33 @@ def test_gelu_epilogue_against_the_erf_form(F, tile, step):
     assert torch.equal(yc[x >= 8], x[x >= 8]) and bool((yc[x <= -8].abs() < 1e-10).all()) and yc[x == 0].item() == 0.0
 
 
+def test_gemm_bf16_stream_random_shapes(F):
+    """the stream kernel (tile hint 256257) on 24 seeded random shapes with ragged edges in every dimension (M any, N and K multiples
+    of 8, K from one k-tile to several), every epilogue it takes, with and without bias"""
+    rng = np.random.RandomState(20261005)
+    for case in range(24):
+        M = int(rng.randint(1, 2600))
+        N = 8 * int(rng.randint(1, 130))
+        K = 8 * int(rng.randint(1, 160))
+        epi = [0, 1, 4, 5][case % 4]
+        use_bias = bool(rng.randint(0, 2)) and epi != 4
+        a, b = rb(rnd(M, K, seed=case)), rb(rnd(N, K, seed=100 + case, scale=K ** -0.5))
+        bias = rnd(N, seed=200 + case).float().double() if use_bias else None
+        h = a @ b.T + (bias if use_bias else 0.0)
+        kw = dict(bias=bias.float().cuda()) if use_bias else {}
+        with knobs(gemm_bf16_tile=256257):
+            if epi == 5:
+                g, pre = F.op_gemm_bf16(5, dbf(a), dbf(b), want_c2=True, **kw)
+                close(pre, h, atol=1e-5, rtol=2 ** -8, msg=f"case {case} pre {M}x{N}x{K}")
+                close(g, O.gelu_exact(h), atol=5e-5, rtol=2 ** -8, msg=f"case {case} gelu2 {M}x{N}x{K}")
+            else:
+                y = F.op_gemm_bf16(epi, dbf(a), dbf(b), **kw)
+                if epi == 4:
+                    close(y, h, atol=2e-5 * K ** 0.5, msg=f"case {case} f32 {M}x{N}x{K}")
+                else:
+                    close(y, O.gelu_exact(h) if epi == 1 else h, atol=5e-5, rtol=2 ** -8, msg=f"case {case} epi {epi} {M}x{N}x{K}")
+
+
 def test_gemm_bf16_identity_asymmetric(F, mfma16):
     """A = I with an asymmetric integer B catches any row/column or k-order mix-up exactly"""
     n = 512
