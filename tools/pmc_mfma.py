@@ -18,7 +18,7 @@ import glob
 import json
 import sys
 
-FAMILIES = ("gemm_f32_kernel", "gemm_bf16_stream_kernel", "gemm_bf16_ring_kernel", "gemm_bf16_kernel", "attn_fwd_kernel", "attn_bwd_kernel", "attn_bwd64_kernel",
+FAMILIES = ("gemm_f32_kernel", "gemm_bf16_stream_kernel", "gemm_bf16_ring_kernel", "gemm_bf16_kernel", "attn_fwd_pipe_kernel", "attn_fwd_kernel", "attn_bwd_kernel", "attn_bwd64_kernel",
             "attn_fwd_bf16_stream", "attn_fwd_bf16",
             "attn_bwd_dq_bf16", "attn_bwd_dkv_bf16")
 SIMDS = 256 * 4
