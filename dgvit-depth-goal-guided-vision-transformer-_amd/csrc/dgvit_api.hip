@@ -18,7 +18,7 @@ long long* g_gemm_stamps = nullptr;
 int g_gemm_stamp_capacity = 0;
 long long g_gemm_persist_launches = 0;
 int g_group_reduce = 1, g_ln_fusion = 1, g_conv_gather = 1, g_small_path = 0, g_small_path_max_rows = 4160;
-int g_gemm_bf16_tile_hint = 0, g_gemm_bf16_m16 = 1, g_gemm_bf16_group_m = 8, g_attn_bwd64 = 1;
+int g_gemm_bf16_tile_hint = 0, g_gemm_bf16_m16 = 1, g_gemm_bf16_group_m = 8, g_attn_bwd64 = 1, g_gemm_bf16_l2_budget_kb = 2048;
 long long* g_gemm_bf16_stamps = nullptr;
 #endif
 static inline bool dense_last_block(const dgvit_config* c) { return (c->flags & DGVIT_FLAG_DENSE_LAST_BLOCK) != 0; }
@@ -144,6 +144,7 @@ int wgrad(const float* A, int lda, const float* B, int ldb, float* dW, float* db
 
 struct Dims {
   int B, P, N, D, I, M, L, H, dh, pd, pool_mean;
+  int proj;       // 0: heads == 1 and dim_head == dim -- the reference's Attention has no output projection (to_out = nn.Identity(), GoalFormer.py:56,66-69)
   long long T;
 };
 
@@ -182,6 +183,7 @@ int make_dims(const dgvit_config* c, int batch, Dims& d) {
   d.D = c->dim; d.H = c->heads; d.dh = c->dim_head; d.I = d.H * d.dh; d.M = c->mlp_dim; d.L = c->depth;
   d.pd = c->patch_h * c->patch_w;
   d.pool_mean = c->pool_mean ? 1 : 0;
+  d.proj = !(d.H == 1 && d.dh == d.D);
   d.T = (long long)batch * d.N;
   DGVIT_CHECK_ARG(d.N <= 224, "tokens N=%d exceeds the fused-attention limit (224)", d.N);
   DGVIT_CHECK_ARG(d.T < (1ll << 31) && d.T * (long long)(3 * d.I > d.M ? 3 * d.I : d.M) < (1ll << 40), "batch too large");
@@ -296,6 +298,7 @@ extern "C" void dgvit_set_gemm_bf16_mfma16(int on) { g_gemm_bf16_m16 = on ? 1 : 
 extern "C" void dgvit_set_attention_bwd_single_pass(int on) { g_attn_bwd64 = on ? 1 : 0; }
 extern "C" void dgvit_set_gemm_bf16_group_m(int rows) { g_gemm_bf16_group_m = rows > 0 ? rows : 8; }
 extern "C" void dgvit_set_gemm_bf16_stamps(long long* stamps) { g_gemm_bf16_stamps = stamps; }
+extern "C" void dgvit_set_gemm_bf16_l2_budget_kb(int kb) { g_gemm_bf16_l2_budget_kb = kb > 0 ? kb : 0; }
 #endif   // DGVIT_DIAG
 
 // ---------------------------------------------------------------------------------------------- encoder
@@ -360,6 +363,12 @@ extern "C" long long dgvit_got_backward_scratch_floats(const dgvit_config* cfg, 
 
 enum { P_POS = 0, P_PW = 1, P_PB = 2, P_RMS = 3, P_L0 = 4 };
 enum { L_LN1W = 0, L_LN1B, L_QKV, L_OUTW, L_OUTB, L_LN2W, L_LN2B, L_FC1W, L_FC1B, L_FC2W, L_FC2B };
+// the to_out slots of the parameter table are unused (may be NULL) when the attention has no output projection
+static inline bool no_projection_slot(const Dims& d, int i) {
+  if (d.proj || i < P_L0) return false;
+  const int j = (i - P_L0) % DGVIT_PARAMS_PER_LAYER;
+  return j == L_OUTW || j == L_OUTB;
+}
 
 extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* params, const float* img, const float* goal,
                                  float* feat, float* ws, long long ws_floats, int batch, int save, float keep,
@@ -371,7 +380,7 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
   DGVIT_CHECK_ARG(keep > 0.f && keep <= 1.f, "dropout_keep must be in (0, 1]");
   const Ws w = make_ws(d, save);
   if (ws_floats < w.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "forward workspace %lld < %lld floats", ws_floats, w.total);
-  for (int i = 0; i < P_L0 + DGVIT_PARAMS_PER_LAYER * d.L; ++i) DGVIT_CHECK_ARG(params[i], "parameter %d is null", i);
+  for (int i = 0; i < P_L0 + DGVIT_PARAMS_PER_LAYER * d.L; ++i) DGVIT_CHECK_ARG(params[i] || no_projection_slot(d, i), "parameter %d is null", i);
   const int T = (int)d.T;
 
   SplitBuf sk;
@@ -408,7 +417,7 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
 
   // inference on a handful of frames (SAC.choose_action, the no-grad passes of learn() at batch 32): two launches per block
 #ifdef DGVIT_DIAG   // (measured slower than the schedule below, DESIGN 3.7: not in the product library)
-  if (!save && g_small_path && !d.pool_mean && d.T <= g_small_path_max_rows && frame_path_supports(d.B, d.N, d.D, d.H, d.dh, d.M))
+  if (!save && g_small_path && !d.pool_mean && d.proj && d.T <= g_small_path_max_rows && frame_path_supports(d.B, d.N, d.D, d.H, d.dh, d.M))
     return frame_path_forward(x, params, d.L, ws + w.layer0, feat, d.B, d.N, d.D, d.H, d.dh, d.M, st);
 #endif
 
@@ -441,7 +450,10 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
       TRY(gemm_f32(GEMM_NT, EPI_STORE, q, 1, st));
     }
     TRY(attention_fwd(lb + w.qkv, lb + w.ao, save ? lb + w.lse : nullptr, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
-    {
+    if (!d.proj) {
+      // to_out = nn.Identity() (GoalFormer.py:56,66-69): the head's output IS the branch output (I == D): xmid = attn + x (:103)
+      TRY(add_rows(lb + w.ao, (long long)rs * d.I, x, (long long)rs * d.D, lb + w.xmid, (long long)rs * d.D, tok, d.D, st));
+    } else {
       GemmParams p = gp(lb + w.ao, rs * d.I, lp[L_OUTW], d.I, lb + w.xmid, rs * d.D, tok, d.D, d.I);
       p.bias = lp[L_OUTB]; p.res = x; p.ldr = rs * d.D;
       if (ln_fused) {
@@ -452,7 +464,7 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
       TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
     }
     // x = ff(LN(x)) + x     (GoalFormer.py:104, 42-50)
-    if (!ln_fused) TRY(layernorm_fwd(lb + w.xmid, lp[L_LN2W], lp[L_LN2B], lb + w.ln2, lb + w.mean2, lb + w.rstd2, tok, d.D, 1e-5f, rs, st));
+    if (!ln_fused || !d.proj) TRY(layernorm_fwd(lb + w.xmid, lp[L_LN2W], lp[L_LN2B], lb + w.ln2, lb + w.mean2, lb + w.rstd2, tok, d.D, 1e-5f, rs, st));
     {
       GemmParams p = gp(lb + w.ln2, rs * d.D, lp[L_FC1W], d.D, lb + w.h1, d.M, tok, d.M, d.D);   // h1 / a1 are dense (tok, M)
       p.bias = lp[L_FC1B]; p.C2 = lb + w.a1; p.ldc2 = d.M;
@@ -533,7 +545,7 @@ extern "C" int dgvit_got_backward_ev(const dgvit_config* cfg, const float* const
   if (ws_floats < w.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "backward workspace %lld < %lld floats", ws_floats, w.total);
   if (scratch_floats < s.total) return dgvit_set_error(DGVIT_ERR_WORKSPACE, "backward scratch %lld < %lld floats", scratch_floats, s.total);
   const int np = P_L0 + DGVIT_PARAMS_PER_LAYER * d.L;
-  for (int i = 0; i < np; ++i) DGVIT_CHECK_ARG(params[i], "parameter %d is null", i);   // grads[i] == NULL: frozen parameter, its gradient is skipped
+  for (int i = 0; i < np; ++i) DGVIT_CHECK_ARG(params[i] || no_projection_slot(d, i), "parameter %d is null", i);   // grads[i] == NULL: frozen parameter, its gradient is skipped
   const int T = (int)d.T;
   float* dx = scratch + s.dxa;    // gradient of the residual stream entering the current op
   float* dx2 = scratch + s.dxb;
@@ -607,14 +619,15 @@ extern "C" int dgvit_got_backward_ev(const dgvit_config* cfg, const float* const
     TRY(layernorm_bwd(dln, lb + w.xmid, lb + w.mean2, lb + w.rstd2, lp[L_LN2W], dx, dx2, lg[L_LN2W], lg[L_LN2B], scratch + s.part_ln2, tok, d.D,
                       rs, st, gq));
     // ---- attention branch: xmid = to_out(attn(to_qkv(ln1))) + xin       (dx2 = d xmid)
-    TRY(fork());
-    TRY(wgrad(dx2, rs * d.D, lb + w.ao, rs * d.I, lg[L_OUTW], lg[L_OUTB], d.D, d.I, tok, slabs + s.sl_out, s.n_out, sw, gq));
-    {
+    if (d.proj) {
+      TRY(fork());
+      TRY(wgrad(dx2, rs * d.D, lb + w.ao, rs * d.I, lg[L_OUTW], lg[L_OUTB], d.D, d.I, tok, slabs + s.sl_out, s.n_out, sw, gq));
       GemmParams p = gp(dx2, rs * d.D, lp[L_OUTW], d.I, dao, rs * d.I, tok, d.I, d.D);
       sk.attach(p);
       TRY(gemm_f32(GEMM_NN, EPI_STORE, p, 1, st));  // dao = dxmid Wo
     }
-    TRY(attention_bwd(lb + w.qkv, lb + w.ao, dao, lb + w.lse, dqkv, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
+    // (no output projection: the gradient of the attention output is the residual-stream gradient itself, I == D)
+    TRY(attention_bwd(lb + w.qkv, lb + w.ao, d.proj ? dao : dx2, lb + w.lse, dqkv, d.B, d.N, d.H, d.dh, last ? 1 : d.N, st));
     TRY(fork());
     if (!last) {
       TRY(wgrad(dqkv, 3 * d.I, lb + w.ln1, d.D, lg[L_QKV], nullptr, 3 * d.I, d.D, T, slabs + s.sl_qkv, s.n_qkv, sw, gq));
@@ -1057,6 +1070,7 @@ Wsb make_wsb(const Dims& d, int save) {
 
 int check_bf16_dims(const Dims& d) {
   DGVIT_CHECK_ARG(d.dh == 64, "bf16 path: dim_head=%d unsupported (64)", d.dh);
+  DGVIT_CHECK_ARG(d.proj, "bf16 path: heads == 1 with dim_head == dim (attention without output projection) runs on the fp32 path only");
   DGVIT_CHECK_ARG(d.D % 8 == 0 && d.M % 8 == 0 && d.pd % 8 == 0, "bf16 path: dim, mlp_dim and patch pixels must be multiples of 8");
   return DGVIT_OK;
 }

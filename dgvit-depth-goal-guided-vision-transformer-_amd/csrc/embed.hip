@@ -67,6 +67,18 @@ __global__ void __launch_bounds__(256) relu_bwd_kernel(const float* __restrict__
   if (i < n) out[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 
+// out[r][:] = a[r][:] + b[r][:] over `rows` rows of `row4` float4 with independent row strides (in float4): the residual add of an
+// Attention whose to_out is nn.Identity() (heads == 1 and dim_head == dim, GoalFormer.py:56,66-69,103)
+__global__ void __launch_bounds__(256) add_rows_kernel(const float4* __restrict__ a, long long lda4, const float4* __restrict__ b, long long ldb4,
+                                                       float4* __restrict__ out, long long ldo4, long long total4, int row4) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const long long r = i / row4;
+  const int c = (int)(i - r * row4);
+  const float4 x = a[r * lda4 + c], y = b[r * ldb4 + c];
+  out[r * ldo4 + c] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+
 // out[i][:] = src[idx[i]][:] for rows of `row4` float4 (device-resident replay sampling)
 __global__ void __launch_bounds__(256) gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ idx,
                                                           float* __restrict__ out, long long total4, int row4, long long nrows) {
@@ -89,6 +101,16 @@ int gather_rows(const float* src, const long long* idx, float* out, long long ns
   hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, src, idx, out, total4,
                      (int)(row_floats / 4), nrows);
   DGVIT_CHECK_LAUNCH("gather_rows");
+  return DGVIT_OK;
+}
+
+int add_rows(const float* a, long long lda, const float* b, long long ldb, float* out, long long ldo, long long rows, int cols, hipStream_t stream) {
+  DGVIT_CHECK_ARG(a && b && out && rows > 0 && cols > 0, "add_rows: bad arguments");
+  DGVIT_CHECK_ARG(cols % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldo % 4 == 0, "add_rows: row length and strides must be multiples of 4 floats");
+  const long long total4 = rows * (cols / 4);
+  hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const float4*>(a), lda / 4,
+                     reinterpret_cast<const float4*>(b), ldb / 4, reinterpret_cast<float4*>(out), ldo / 4, total4, cols / 4);
+  DGVIT_CHECK_LAUNCH("add_rows");
   return DGVIT_OK;
 }
 

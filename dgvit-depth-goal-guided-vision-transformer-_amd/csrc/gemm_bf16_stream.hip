@@ -130,8 +130,30 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
   const int wr = wave >> 2, wc = wave & 3;          // wave tile: rows 128 wr .. + 127, columns 64 wc .. + 63
   const int l15 = lane & 15, q = lane >> 4;
   const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
-  // tile order inside an XCD's chunk: groups of group_m row panels walked column by column (their A and B k-slices share the L2)
+  // Tile order (the XCDs take contiguous chunks of it, xcd_chunk): COLUMN BLOCKS of the tile grid, each walked row panel by row panel
+  // with the block's columns innermost.  The 32 workgroups of an XCD then work on (32 / width) row panels x the block's `width` column
+  // tiles at a time: the block's B panels (width x 256 x K bf16, sized by the launcher to stay well inside the 4 MB L2) are re-used by
+  // every row panel that follows, and an A panel is fetched once per column block and shared by the block's columns as it streams
+  // through.  (Round 3 walked groups of 8 row panels column by column: 8 A panels + 4 B panels of a K = 768 GEMM are 4.7 MB, nothing
+  // survived from one round of tiles to the next, 1.7 x the algorithmic bytes went past the L2s.)  p.col_blocks == 0 keeps that older
+  // walk (groups of group_m row panels) for A/B in the diagnostic build.
   auto tile_mn = [&](int t, int& m0, int& n0) {
+    if (p.col_blocks > 0) {
+      const int nb = p.col_blocks, wq = tiles_n / nb, wrem = tiles_n - wq * nb;      // the first wrem blocks are wq + 1 columns wide
+      const int big = tiles_m * (wq + 1);
+      int w, c0, rem;
+      if (t < wrem * big) {
+        const int b = t / big;
+        rem = t - b * big, w = wq + 1, c0 = b * (wq + 1);
+      } else {
+        const int t2 = t - wrem * big, small = tiles_m * wq, b = t2 / small;
+        rem = t2 - b * small, w = wq, c0 = wrem * (wq + 1) + b * wq;
+      }
+      const int r = rem / w;
+      m0 = r * 256;
+      n0 = (c0 + rem - r * w) * 256;
+      return;
+    }
     const int GROUP_M = p.group_m;
     const int per_group = GROUP_M * tiles_n, grp_i = t / per_group, within = t - grp_i * per_group;
     const int rows = tiles_m - grp_i * GROUP_M < GROUP_M ? tiles_m - grp_i * GROUP_M : GROUP_M;
@@ -493,6 +515,15 @@ int launch_stream(const GemmBf16Params& p_in, hipStream_t st) {
 #endif
   if (p.group_m <= 0) p.group_m = g_gemm_bf16_group_m > 0 ? g_gemm_bf16_group_m % 1000 : 8;
   if (p.group_m <= 0) p.group_m = 8;
+  {   // column blocks of the tile walk (see tile_mn): as few as keep a block's B panels inside the L2 budget; when not even four
+      // columns fit (K = 3072: 1.5 MB per panel) persistence across rounds of tiles is out of reach and ONE block keeps what the
+      // workgroups can still share, the k-slices they read at the same time
+    const int tiles_n = (p.N + 255) / 256;
+    const long long panel = 256ll * p.K * 2;
+    const long long budget = (long long)g_gemm_bf16_l2_budget_kb * 1024;
+    int fit = (int)(budget / panel);
+    p.col_blocks = budget <= 0 ? 0 : (fit >= tiles_n || fit < 4) ? 1 : (tiles_n + fit - 1) / fit;
+  }
   const long long tiles = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   {   // de-phasing of the workgroups (see the kernel): `phases` start times a fraction of a tile period apart (the period estimated
       // from the measured ~2300 cycles per k-tile).  With ordinary output stores 8 phases were worth +3..7 % at 12 and 16 tiles per CU

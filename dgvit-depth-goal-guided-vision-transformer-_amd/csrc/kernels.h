@@ -15,6 +15,7 @@ int colsum(const float*, long long, float*, float*, int, int, int, hipStream_t);
 int attention_fwd(const float*, float*, float*, int, int, int, int, int, hipStream_t);
 int attention_bwd(const float*, const float*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
 int patchify(const float*, float*, int, int, int, int, int, hipStream_t);
+int add_rows(const float*, long long, const float*, long long, float*, long long, long long, int, hipStream_t);
 int goal_row(const float*, const float*, float*, int, int, int, hipStream_t);
 int dropout_inplace(float*, long long, unsigned long long, const unsigned long long*, float, hipStream_t);
 int relu_bwd(const float*, const float*, float*, long long, hipStream_t);

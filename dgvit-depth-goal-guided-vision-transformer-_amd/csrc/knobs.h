@@ -36,6 +36,7 @@ DGVIT_KNOB(int, g_small_path_max_rows, 4160)
 DGVIT_KNOB(int, g_gemm_bf16_tile_hint, 0)       // bf16 GEMM tile (0 = automatic)
 DGVIT_KNOB(int, g_gemm_bf16_m16, 1)             // ring GEMM on v_mfma_f32_16x16x32_bf16 (0: 32x32x16)
 DGVIT_KNOB(int, g_gemm_bf16_group_m, 8)         // row panels per walk group of the persistent tile order
+DGVIT_KNOB(int, g_gemm_bf16_l2_budget_kb, 2048)  // stream GEMM: L2 bytes a column block's B panels may take (0 = the round-3 group_m walk)
 DGVIT_KNOB(long long*, g_gemm_bf16_stamps, nullptr)
 DGVIT_KNOB(int, g_attn_bwd64, 1)                // single-pass fp32 attention backward for 32 < N <= 64
 #ifdef DGVIT_DIAG

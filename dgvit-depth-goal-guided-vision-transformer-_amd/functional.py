@@ -32,8 +32,9 @@ def _ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
-def _table(tensors: Sequence[torch.Tensor]):
-    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+def _table(tensors: Sequence[Optional[torch.Tensor]]):
+    """device-pointer table; a None entry (an unused slot, e.g. to_out of a projection-less attention) is a NULL pointer"""
+    return (ctypes.c_void_p * len(tensors))(*[0 if t is None else t.data_ptr() for t in tensors])
 
 
 def _empty_batch(shape, tensors):
@@ -67,6 +68,7 @@ def _flat_grads(params, needs, dev):
     weight-gradient work.  The buffer is zero-filled so that the padding lanes between slots stay finite for whoever
     consumes the flat buffer as a whole (Adam moments, all-reduce)."""
     offs, off = [], 0
+    needs = [bool(need) and p is not None for p, need in zip(params, needs)]
     for p, need in zip(params, needs):
         offs.append(off)
         if need:
@@ -135,7 +137,7 @@ class _GoTEncoder(torch.autograd.Function):
         lib = _lib.load()
         cfg = dgvit_config(*cfg_tuple)
         img, goal = _dev(img, "img"), _dev(goal, "goal")
-        params = [_dev(p, f"param[{i}]") for i, p in enumerate(params)]
+        params = [None if p is None else _dev(p, f"param[{i}]") for i, p in enumerate(params)]   # (None: unused to_out slots, dgvit_hip.h)
         nparam = _lib.NUM_GLOBAL_PARAMS + _lib.PARAMS_PER_LAYER * cfg.depth
         if len(params) != nparam:
             raise DgvitError(f"expected {nparam} parameter tensors, got {len(params)}")
@@ -199,7 +201,7 @@ def got_encoder(img, goal, cfg_tuple, params, dropout_keep=1.0, dropout_seed=0, 
     (include/dgvit_hip.h: dgvit_grad_events) -- parallel.GradSync(overlap=True) starts the blocks' all-reduces there."""
     if img.shape[0] == 0:
         return _empty_batch((0, int(cfg_tuple[4])), [img, goal, *params])
-    need_grad = torch.is_grad_enabled() and (goal.requires_grad or any(p.requires_grad for p in params))
+    need_grad = torch.is_grad_enabled() and (goal.requires_grad or any(p is not None and p.requires_grad for p in params))
     return _GoTEncoder.apply(img, goal, tuple(cfg_tuple), dropout_keep, dropout_seed, need_grad, grad_hook, *params)
 
 
@@ -800,6 +802,9 @@ class _GoTEncoderBf16(torch.autograd.Function):
 
 def got_encoder_bf16(img, goal, cfg_tuple, params, weights: Bf16Weights, dropout_keep=1.0, dropout_seed=0, grad_hook=None):
     """GoT.forward in the bf16 configuration (bf16 storage of GEMM operands, fp32 master parameters and gradients)."""
+    if any(p is None for p in params):
+        raise NotImplementedError("the bf16 configuration needs an attention with an output projection (heads == 1 with dim_head == dim "
+                                  "runs on the fp32 path only)")
     if img.shape[0] == 0:
         return _empty_batch((0, int(cfg_tuple[4])), [img, goal, *params])
     need_grad = torch.is_grad_enabled() and (goal.requires_grad or any(p.requires_grad for p in params))

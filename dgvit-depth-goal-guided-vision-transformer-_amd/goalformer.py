@@ -9,6 +9,7 @@ Differences from the reference, on purpose:
   * ``patch_size`` is honoured (the reference hard-wires 16x20 / Linear(320, dim), GoalFormer.py:137-139);
     with patch_size=(16, 20) the parameter shapes are identical;
   * transformer ``dropout`` must be 0 (the only value the reference's nets ever use); ``pool`` 'cls' and 'mean' both work;
+  * ``heads == 1 and dim_head == dim`` gives the reference's projection-less attention (``to_out = nn.Identity()``) on the fp32 path;
   * ``RMSNorm`` also works stand-alone (``unit_offset`` included).
 """
 import math
@@ -58,11 +59,12 @@ class Attention(_Holder):
     def __init__(self, dim, heads=8, dim_head=64, dropout=0.):
         super().__init__()
         inner = dim_head * heads
-        if heads == 1 and dim_head == dim:
-            raise NotImplementedError("heads == 1 with dim_head == dim drops to_out in the reference (GoalFormer.py:56); unsupported")
+        project_out = not (heads == 1 and dim_head == dim)      # GoalFormer.py:56
         self.heads, self.scale = heads, dim_head ** -0.5
         self.to_qkv = nn.Linear(dim, inner * 3, bias=False)
-        self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout))
+        # GoalFormer.py:66-69: without a projection ``to_out`` is nn.Identity() -- no ``to_out`` keys in the state_dict, and the fused
+        # encoder adds the head's output straight into the residual stream (param_table passes None for the two slots)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout)) if project_out else nn.Identity()
 
 
 class FeedForward(_Holder):
@@ -168,7 +170,8 @@ class GoT(nn.Module):
         """Parameters in the order of include/dgvit_hip.h's table."""
         t = [self.pos_embedding, self.to_patch_embedding[1].weight, self.to_patch_embedding[1].bias, self.layer_norm.g]
         for attn, ff in self.transformer.layers:
-            t += [attn.norm.weight, attn.norm.bias, attn.fn.to_qkv.weight, attn.fn.to_out[0].weight, attn.fn.to_out[0].bias,
+            out = attn.fn.to_out[0] if isinstance(attn.fn.to_out, nn.Sequential) else None    # None: nn.Identity(), the slots stay empty
+            t += [attn.norm.weight, attn.norm.bias, attn.fn.to_qkv.weight, out.weight if out else None, out.bias if out else None,
                   ff.norm.weight, ff.norm.bias, ff.fn.net[0].weight, ff.fn.net[0].bias, ff.fn.net[3].weight, ff.fn.net[3].bias]
         return t
 

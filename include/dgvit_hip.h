@@ -80,7 +80,10 @@ typedef struct dgvit_config {
  *   +5 LN2 weight (D) [1.norm.weight]   +6 LN2 bias (D) [1.norm.bias]
  *   +7 MLP fc1 weight (M, D) [1.fn.net.0.weight]    +8 fc1 bias (M) [1.fn.net.0.bias]
  *   +9 MLP fc2 weight (D, M) [1.fn.net.3.weight]    +10 fc2 bias (D) [1.fn.net.3.bias]
- * cls_token and mlp_head.* never take part in the forward (GoalFormer.py:143,151-154) and are not passed. */
+ * cls_token and mlp_head.* never take part in the forward (GoalFormer.py:143,151-154) and are not passed.
+ * heads == 1 and dim_head == dim: the reference's Attention has NO output projection (to_out = nn.Identity(), GoalFormer.py:56,66-69);
+ * slots +3 / +4 are then ignored in both tables (pass NULL) and the attention output joins the residual stream directly (fp32 path;
+ * the bf16 entry points refuse that shape). */
 #define DGVIT_NUM_GLOBAL_PARAMS 4
 #define DGVIT_PARAMS_PER_LAYER 11
 

@@ -62,6 +62,9 @@ void dgvit_set_small_batch_path(int on, int max_rows);
 void dgvit_set_gemm_bf16_tile(int tile);
 /* test/bench knob: row panels per walk group of the persistent bf16 GEMM's tile order (default 8) */
 void dgvit_set_gemm_bf16_group_m(int rows);
+/* A/B knob: L2 bytes (KB) that the B panels of one column block of the stream GEMM's tile walk may take (default 2048; the launcher
+ * cuts the tile grid into as few column blocks as fit); 0 = the round-3 walk (groups of group_m row panels, column by column) */
+void dgvit_set_gemm_bf16_l2_budget_kb(int kb);
 /* A/B knob: 1 (default) the single-pass fp32 attention backward for 32 < N <= 64 (every tile pair computed once); 0 the two-phase
  * kernel for every shape.  Same results up to summation order. */
 void dgvit_set_attention_bwd_single_pass(int on);

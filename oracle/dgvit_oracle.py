@@ -80,6 +80,11 @@ class GoTConfig:
     def inner(self) -> int:
         return self.heads * self.dim_head
 
+    @property
+    def project_out(self) -> bool:
+        """GoalFormer.py:56: ``project_out = not (heads == 1 and dim_head == dim)``; False => ``to_out = nn.Identity()`` (:66-69)."""
+        return not (self.heads == 1 and self.dim_head == self.dim)
+
     def fwd_flops_per_frame(self) -> float:
         """GEMM-only forward FLOPs per frame (SURVEY.md section 8(d) formula)."""
         P, pd, D, L = self.num_patches, self.patch_dim, self.dim, self.depth
@@ -107,8 +112,11 @@ def got_param_spec(cfg: GoTConfig, prefix: str = "trans.") -> List[Tuple[str, Tu
             (lp + "0.norm.weight", (D,), "gain"),                     # GoalFormer.py:34
             (lp + "0.norm.bias", (D,), "lnbias"),
             (lp + "0.fn.to_qkv.weight", (3 * I, D), "xavier"),        # GoalFormer.py:64
-            (lp + "0.fn.to_out.0.weight", (D, I), "xavier"),          # GoalFormer.py:66-69
-            (lp + "0.fn.to_out.0.bias", (D,), "bias"),
+        ]
+        if cfg.project_out:                                           # GoalFormer.py:56,66-69: nn.Identity() has no parameters
+            s += [(lp + "0.fn.to_out.0.weight", (D, I), "xavier"),
+                  (lp + "0.fn.to_out.0.bias", (D,), "bias")]
+        s += [
             (lp + "1.norm.weight", (D,), "gain"),
             (lp + "1.norm.bias", (D,), "lnbias"),
             (lp + "1.fn.net.0.weight", (M, D), "xavier"),             # GoalFormer.py:43
@@ -242,8 +250,8 @@ def rms_norm(x: Tensor, g: Tensor) -> Tensor:
     return x / n * math.sqrt(x.shape[-1]) * g
 
 
-def attention(x: Tensor, w_qkv: Tensor, w_out: Tensor, b_out: Tensor, heads: int, dim_head: int) -> Tensor:
-    """Attention.forward (GoalFormer.py:71-82).
+def attention(x: Tensor, w_qkv: Tensor, w_out: Optional[Tensor], b_out: Optional[Tensor], heads: int, dim_head: int) -> Tensor:
+    """Attention.forward (GoalFormer.py:71-82).  ``w_out is None``: ``to_out`` is ``nn.Identity()`` (GoalFormer.py:56,66-69).
 
     to_qkv rows are ordered [q(h0..hH-1) | k | v], 64 columns per head
     (chunk(3) then 'b n (h d) -> b h n d', GoalFormer.py:72-73).
@@ -257,7 +265,9 @@ def attention(x: Tensor, w_qkv: Tensor, w_out: Tensor, b_out: Tensor, heads: int
     attn = torch.softmax(dots, dim=-1)                       # :77
     out = attn @ v                                           # :80
     out = out.permute(0, 2, 1, 3).reshape(B, N, I)           # :81
-    return linear(out, w_out, b_out)                         # :82 (project_out True when heads*64 != dim or heads>1)
+    if w_out is None:                                        # :66-69 project_out False (heads == 1 and dim_head == dim)
+        return out
+    return linear(out, w_out, b_out)                         # :82
 
 
 def feed_forward(x: Tensor, w1, b1, w2, b2) -> Tensor:
@@ -288,8 +298,8 @@ def got_block(p: Dict[str, Tensor], x: Tensor, i: int, cfg: GoTConfig, prefix: s
     """One Transformer layer: x = attn(LN(x)) + x; x = ff(LN(x)) + x (GoalFormer.py:101-105)."""
     lp = f"{prefix}transformer.layers.{i}."
     h = layer_norm(x, p[lp + "0.norm.weight"], p[lp + "0.norm.bias"])
-    x = attention(h, p[lp + "0.fn.to_qkv.weight"], p[lp + "0.fn.to_out.0.weight"],
-                  p[lp + "0.fn.to_out.0.bias"], cfg.heads, cfg.dim_head) + x
+    x = attention(h, p[lp + "0.fn.to_qkv.weight"], p.get(lp + "0.fn.to_out.0.weight"),
+                  p.get(lp + "0.fn.to_out.0.bias"), cfg.heads, cfg.dim_head) + x
     h = layer_norm(x, p[lp + "1.norm.weight"], p[lp + "1.norm.bias"])
     x = feed_forward(h, p[lp + "1.fn.net.0.weight"], p[lp + "1.fn.net.0.bias"],
                      p[lp + "1.fn.net.3.weight"], p[lp + "1.fn.net.3.bias"]) + x

@@ -238,29 +238,46 @@ def case_cnn(name, kind, batch, seed, image=(128, 160)):
 
 def main():
     C = O.GoTConfig
+    cases = []
+
+    def add(fn, name, *a, **k):
+        cases.append((name, lambda: fn(name, *a, **k)))
+
     # tiny, arbitrary dims (bare GoT; dim_head 32, the smallest the fused attention kernel takes), full gradients
     tiny = C(image=(16, 24), patch=(8, 8), dim=32, depth=2, heads=2, dim_head=32, mlp_dim=64)
-    case_got("got_tiny_eval", tiny, 3, 0, full_grads=True)
-    case_got("got_tiny_mask", tiny, 3, 1, with_mask=True, full_grads=True)
-    case_got("got_tiny_meanpool", tiny, 3, 2, full_grads=True, pool='mean')
+    add(case_got, "got_tiny_eval", tiny, 3, 0, full_grads=True)
+    add(case_got, "got_tiny_mask", tiny, 3, 1, with_mask=True, full_grads=True)
+    add(case_got, "got_tiny_meanpool", tiny, 3, 2, full_grads=True, pool='mean')
     # patch sizes BASELINE leaves open for 84x84 (N = 50 / 37 / 145 / 197), small width
     for ps in (12, 14, 7, 6):
-        case_got(f"got_84p{ps}", C(image=(84, 84), patch=(ps, ps), dim=64, depth=1, heads=2), 2, 10 + ps)
+        add(case_got, f"got_84p{ps}", C(image=(84, 84), patch=(ps, ps), dim=64, depth=1, heads=2), 2, 10 + ps)
     # native 128x160, unmodified reference classes (C0a shipped, C0b small)
-    case_policy("policy_native_shipped", C(dim=64, depth=4, heads=4), 2, 3407)
-    case_policy("policy_native_small", C(dim=256, depth=6, heads=8), 2, 3408)
-    case_det("detpolicy_native_shipped", C(dim=64, depth=4, heads=4), 2, 3409)
+    add(case_policy, "policy_native_shipped", C(dim=64, depth=4, heads=4), 2, 3407)
+    add(case_policy, "policy_native_small", C(dim=256, depth=6, heads=8), 2, 3408)
+    add(case_det, "detpolicy_native_shipped", C(dim=64, depth=4, heads=4), 2, 3409)
+    # heads == 1 and dim_head == dim: Attention.to_out is nn.Identity() (GoalFormer.py:56,66-69) -- GoTPolicy(2, 2, 2, 1, 64), unmodified
+    # reference class; and the same corner on the bare encoder with a train-mode mask and full gradients (dim_head 32)
+    add(case_policy, "policy_native_h1", C(dim=64, depth=2, heads=1), 2, 3410)
+    add(case_got, "got_tiny_h1_mask", C(image=(16, 24), patch=(8, 8), dim=32, depth=2, heads=1, dim_head=32, mlp_dim=64), 3, 4,
+        with_mask=True, full_grads=True)
     # C2/C3 shape: 84x84 @ 12, L6 H8 D256
     c2 = C(image=(84, 84), patch=(12, 12), dim=256, depth=6, heads=8)
-    case_policy("policy_c2", c2, 4, 0)
-    case_sac("sac_c2", c2, 4, 0)
-    case_got("got_c2_mask", c2, 2, 5, with_mask=True)
+    add(case_policy, "policy_c2", c2, 4, 0)
+    add(case_sac, "sac_c2", c2, 4, 0)
+    add(case_got, "got_c2_mask", c2, 2, 5, with_mask=True)
     # the shipped CNN critic and the CNN actor, native 128x160 and 84x84
-    case_cnn("cnn_qnet_native", "qnet", 3, 21)
-    case_cnn("cnn_qnet_84", "qnet", 2, 22, image=(84, 84))
-    case_cnn("cnn_policy_native", "policy", 2, 23)
+    add(case_cnn, "cnn_qnet_native", "qnet", 3, 21)
+    add(case_cnn, "cnn_qnet_84", "qnet", 2, 22, image=(84, 84))
+    add(case_cnn, "cnn_policy_native", "policy", 2, 23)
     # C5 shape cut to depth 2: 224x224 @ 16, H12 D768 M3072
-    case_got("got_c5_l2", C(image=(224, 224), patch=(16, 16), dim=768, depth=2, heads=12, mlp_dim=3072), 1, 6)
+    add(case_got, "got_c5_l2", C(image=(224, 224), patch=(16, 16), dim=768, depth=2, heads=12, mlp_dim=3072), 1, 6)
+
+    want = sys.argv[1:]            # `python make_golden.py name ...` regenerates only those cases
+    unknown = [w for w in want if w not in [n for n, _ in cases]]
+    assert not unknown, f"unknown cases {unknown}"
+    for name, run in cases:
+        if not want or name in want:
+            run()
 
 
 if __name__ == "__main__":

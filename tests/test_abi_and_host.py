@@ -111,10 +111,12 @@ def test_no_cpu_fallback(amd):
         m.trans.transformer(torch.zeros(1))
 
 
-@pytest.mark.parametrize("kind", ["policy", "qnet", "detpolicy"])
-def test_state_dict_abi_matches_reference_keys(amd, kind):
-    """Keys, order and shapes equal the reference's (pinned by make_golden.py's strict load into the reference)."""
-    cfg = O.GoTConfig(dim=64, depth=4, heads=4)
+@pytest.mark.parametrize("kind,heads", [("policy", 4), ("qnet", 4), ("detpolicy", 4), ("policy", 1), ("qnet", 1)])
+def test_state_dict_abi_matches_reference_keys(amd, kind, heads):
+    """Keys, order and shapes equal the reference's (pinned by make_golden.py's strict load into the reference); heads == 1 with
+    l_f_size == 64 is the projection-less Attention (to_out = nn.Identity(): no to_out keys, GoalFormer.py:56,66-69)."""
+    cfg = O.GoTConfig(dim=64, depth=4, heads=heads)
+    assert cfg.project_out == (heads != 1)
     ctor = {"policy": amd.GoTPolicy, "qnet": amd.GoTQNetwork, "detpolicy": amd.DeterministicGoTPolicy}[kind]
     spec = {"policy": O.policy_param_spec, "qnet": O.qnet_param_spec, "detpolicy": O.detpolicy_param_spec}[kind](cfg)
     m = ctor(2, 2, cfg.depth, cfg.heads, cfg.dim)
@@ -132,6 +134,8 @@ def test_state_dict_abi_matches_reference_keys(amd, kind):
     assert m.to("cpu") is m
     for attr in ("trans", "fc_embed", "fc1", "fc2"):
         assert hasattr(m, attr)
+    table = m.trans.param_table()
+    assert len(table) == 4 + 11 * cfg.depth and sum(t is None for t in table) == (0 if cfg.project_out else 2 * cfg.depth)
 
 
 def test_init_follows_reference(amd):

@@ -1,0 +1,129 @@
+"""GPU: what round 4 added, through the C ABI.
+
+* Attention without an output projection (heads == 1 and dim_head == dim: to_out = nn.Identity(), GoalFormer.py:56,66-69) against
+  fixtures from the reference's own classes and against the oracle, forward and backward, eval and train mode.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import O, load_fixture, fixture_cfg, got_case_inputs, check_grad_digest  # noqa: E402
+
+OUT_TOL = 1e-4
+GRAD_RTOL = 2e-3
+GRAD_ATOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import dgvit_amd
+    dgvit_amd.load_library()
+    assert torch.cuda.is_available()
+    return dgvit_amd
+
+
+def _build_got(amd, cfg):
+    return amd.GoT(image_size=cfg.image, patch_size=cfg.patch, num_classes=cfg.num_classes, dim=cfg.dim, depth=cfg.depth,
+                   heads=cfg.heads, mlp_dim=cfg.mlp_dim, channels=1, dim_head=cfg.dim_head)
+
+
+# ------------------------------------------------------------------------------------------------ project_out == False
+def test_policy_without_output_projection_golden(amd):
+    """GoTPolicy(2, 2, 2, 1, 64) -- a legal reference constructor call (config.yaml:5 already sets 64) whose Attention has
+    to_out = nn.Identity(): outputs and every gradient digest against the reference's unmodified class."""
+    fx = load_fixture("policy_native_h1")
+    cfg = fixture_cfg(fx)
+    batch, seed = int(fx["meta/batch"]), int(fx["meta/seed"])
+    m = amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim)
+    params = O.make_params(O.policy_param_spec(cfg), seed)
+    assert list(m.state_dict().keys()) == list(params.keys()) and not any("to_out" in k for k in params)
+    m.load_state_dict(params, strict=True)
+    m = m.to("cuda").eval()
+    img, pstate, _, _ = O.make_inputs(cfg, batch, seed)
+    mean, log_std = m([img.cuda(), pstate.cuda()])
+    np.testing.assert_allclose(mean.detach().cpu().numpy(), fx["mean"], rtol=0, atol=OUT_TOL)
+    np.testing.assert_allclose(log_std.detach().cpu().numpy(), fx["log_std"], rtol=0, atol=OUT_TOL)
+    loss = (mean ** 2).mean() + (log_std ** 2).mean()
+    np.testing.assert_allclose(loss.item(), float(fx["loss"]), rtol=1e-4)
+    loss.backward()
+    check_grad_digest(fx, "g", {k: p.grad for k, p in m.named_parameters()}, rtol=GRAD_RTOL, atol=GRAD_ATOL)
+    with torch.no_grad():       # the inference schedule (shared layer buffers, patch gather in the GEMM loader) gives the same outputs
+        mean2, log_std2 = m([img.cuda(), pstate.cuda()])
+    assert torch.equal(mean2, mean.detach()) and torch.equal(log_std2, log_std.detach())
+
+
+def test_got_without_output_projection_train_mode_golden(amd):
+    """Bare encoder, heads 1 / dim_head 32 = dim, train mode with the reference's injected dropout mask: the HIP path cannot take a
+    mask from outside, so it is checked through the oracle (pinned to this fixture at 2e-6 on the CPU): same Philox mask on both sides,
+    outputs 1e-4, every gradient in full."""
+    fx = load_fixture("got_tiny_h1_mask")
+    cfg = fixture_cfg(fx)
+    assert not cfg.project_out
+    seed = int(fx["meta/seed"])
+    params = O.make_params(O.got_param_spec(cfg, prefix=""), seed)
+    m = _build_got(amd, cfg)
+    m.load_state_dict(params, strict=True)
+    m = m.cuda().train()
+    img, goal, wout, _ = got_case_inputs(fx, cfg, False)
+    B = img.shape[0]
+    torch.manual_seed(123)
+    dseed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    torch.manual_seed(123)                      # the module draws the same seed from the CPU generator
+    gg = goal.cuda().requires_grad_(True)
+    feat = m(img.cuda(), gg)
+    (feat * wout.cuda()).sum().backward()
+    ones = torch.ones(B * cfg.tokens * cfg.dim, device="cuda")
+    from dgvit_amd import functional as F
+    mask = (F.op_dropout_(ones, dseed, 0.9) > 0).float().reshape(B, cfg.tokens, cfg.dim).cpu()
+    assert 0.85 < mask.mean().item() < 0.95
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    g2 = goal.clone().requires_grad_(True)
+    ref = O.got_forward(p, img, g2, cfg, drop_mask=mask, prefix="")
+    (ref * wout).sum().backward()
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=OUT_TOL)
+    np.testing.assert_allclose(gg.grad.cpu().numpy(), g2.grad.numpy(), rtol=GRAD_RTOL, atol=1e-4)
+    for k, q in m.named_parameters():
+        if p[k].grad is None:
+            assert q.grad is None or float(q.grad.abs().max()) == 0.0, k
+            continue
+        r = p[k].grad.numpy()
+        np.testing.assert_allclose(q.grad.cpu().numpy(), r, rtol=GRAD_RTOL, atol=2e-5 * max(1.0, float(np.abs(r).max())), err_msg=k)
+
+
+@pytest.mark.parametrize("dense_last", [False, True])
+def test_without_output_projection_schedules_and_larger_batch(amd, dense_last):
+    """B = 40 frames of 84x84 @ 12 (N = 50), depth 3, heads 1, dim 64: the token-0-only last block and the dense schedule both match the
+    oracle (outputs 1e-4, gradients 2e-3); D = 64 also exercises the LayerNorm-in-the-GEMM-epilogue path around the missing to_out GEMM."""
+    cfg = O.GoTConfig(image=(84, 84), patch=(12, 12), dim=64, depth=3, heads=1)
+    params = O.make_params(O.got_param_spec(cfg, prefix=""), 9)
+    m = _build_got(amd, cfg)
+    m.load_state_dict(params, strict=True)
+    m = m.cuda().eval().set_schedule(dense_last_block=dense_last)
+    B = 40
+    img, _, _, _ = O.make_inputs(cfg, B, 9)
+    goal = torch.randn(B, cfg.dim, generator=torch.Generator().manual_seed(2))
+    wout = torch.randn(B, cfg.dim, generator=torch.Generator().manual_seed(3))
+    gg = goal.cuda().requires_grad_(True)
+    feat = m(img.cuda(), gg)
+    (feat * wout.cuda()).sum().backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    g2 = goal.clone().requires_grad_(True)
+    ref = O.got_forward(p, img, g2, cfg, prefix="")
+    (ref * wout).sum().backward()
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=OUT_TOL)
+    np.testing.assert_allclose(gg.grad.cpu().numpy(), g2.grad.numpy(), rtol=GRAD_RTOL, atol=1e-4)
+    for k, q in m.named_parameters():
+        if p[k].grad is None:
+            continue
+        r = p[k].grad
+        err = float((q.grad.cpu() - r).norm() / (r.norm() + 1e-12))
+        assert err < GRAD_RTOL, (k, err)
+
+
+def test_bf16_configuration_refuses_a_projectionless_attention(amd):
+    cfg = O.GoTConfig(image=(84, 84), patch=(12, 12), dim=64, depth=1, heads=1)
+    m = _build_got(amd, cfg).cuda().eval().set_compute_dtype(torch.bfloat16)
+    with pytest.raises(NotImplementedError):
+        m(torch.rand(2, 84, 84, device="cuda"), torch.randn(2, 64, device="cuda"))

@@ -18,7 +18,7 @@ def _leaf_params(spec, seed):
 
 @pytest.mark.parametrize("name,mask", [("got_tiny_eval", False), ("got_tiny_mask", True), ("got_84p12", False),
                                        ("got_84p14", False), ("got_84p7", False), ("got_84p6", False),
-                                       ("got_c2_mask", True), ("got_c5_l2", False)])
+                                       ("got_c2_mask", True), ("got_c5_l2", False), ("got_tiny_h1_mask", True)])
 def test_got_cases(name, mask):
     fx = load_fixture(name)
     cfg = fixture_cfg(fx)
@@ -36,7 +36,7 @@ def test_got_cases(name, mask):
                 np.testing.assert_allclose(v.grad.numpy(), fx[f"gfull/{k}"], rtol=1e-4, atol=2e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["policy_native_shipped", "policy_native_small", "policy_c2"])
+@pytest.mark.parametrize("name", ["policy_native_shipped", "policy_native_small", "policy_c2", "policy_native_h1"])
 def test_policy_cases(name):
     fx = load_fixture(name)
     cfg = fixture_cfg(fx)
@@ -92,6 +92,15 @@ def test_sac_losses_case():
     np.testing.assert_allclose(loss.item(), float(fx["policy_loss"]), rtol=1e-5, atol=1e-6)
     loss.backward()
     check_grad_digest(fx, "ga", {k: v.grad for k, v in pa.items()}, rtol=5e-4, atol=2e-6)
+
+
+def test_identity_to_out_has_no_parameters():
+    """heads == 1 and dim_head == dim: the reference's Attention.to_out is nn.Identity() (GoalFormer.py:56,66-69); the fixture was
+    produced by strict-loading the oracle's parameter spec into the reference's GoTPolicy(2, 2, 2, 1, 64), so the key order is pinned."""
+    cfg = fixture_cfg(load_fixture("policy_native_h1"))
+    assert not cfg.project_out and cfg.heads == 1 and cfg.dim == cfg.dim_head == 64
+    keys = [k for k, _, _ in O.policy_param_spec(cfg)]
+    assert not any("to_out" in k for k in keys) and sum("to_qkv" in k for k in keys) == cfg.depth
 
 
 def test_flop_model_matches_survey():
