@@ -175,6 +175,12 @@ class GoT(nn.Module):
                   ff.norm.weight, ff.norm.bias, ff.fn.net[0].weight, ff.fn.net[0].bias, ff.fn.net[3].weight, ff.fn.net[3].bias]
         return t
 
+    @staticmethod
+    def draw_dropout_seed() -> int:
+        """The Philox seed of one train-mode forward, from torch's CPU generator: follows ``torch.manual_seed`` (ranks seeded with
+        base + rank draw different masks, a rank's sequence repeats) and needs no device sync."""
+        return int(torch.randint(0, 2 ** 62, (1,)).item())
+
     def forward(self, img, goal):
         keep, seed = 1.0, 0
         if self.training and self.dropout.p > 0:
@@ -184,7 +190,7 @@ class GoT(nn.Module):
                 # (graph-safe generator) and let the dropout kernel read it from memory
                 seed = torch.empty(1, dtype=torch.int64, device=img.device).random_()
             else:
-                seed = int(torch.randint(0, 2 ** 62, (1,)).item())   # CPU generator: follows torch.manual_seed, no device sync
+                seed = self.draw_dropout_seed()
         params = self.param_table()
         if self.compute_dtype == torch.bfloat16:
             return F_.got_encoder_bf16(img, goal, self._cfg, params, self._bf16_weights, keep, seed, grad_hook=self._grad_hook)

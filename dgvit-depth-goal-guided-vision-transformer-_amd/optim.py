@@ -13,6 +13,7 @@ followed by all remaining parameters in ``parameters()`` order.  Two networks of
 layout, which is what the one-kernel ``soft_update`` needs.
 """
 import ctypes
+import weakref
 from typing import Iterable, List, Union
 
 import torch
@@ -73,6 +74,11 @@ class _Home:
                 carried.append((i, old, j))
         self.exp_avg = self.exp_avg_sq = self.gflat = None
         self.steps = [0] * len(params)          # per-parameter Adam step counts (torch keeps `state[p]["step"]`)
+        self.owner = [None] * len(params)       # weak reference to the FlatAdam whose state lives in this home's slot (None: nobody's yet)
+        for i, p in enumerate(params):
+            ent = _HOME_OF.get(p)
+            if ent is not None and ent[0] is not self:
+                self.owner[i] = ent[0].owner[ent[1]]
         if carried:
             m, v = self.moments()
             for i, old, j in carried:
@@ -122,6 +128,23 @@ class _Home:
         views = [self.gflat[self.offsets[i]:self.offsets[i] + self.params[i].numel()].view_as(self.params[i]) for i in idx]
         torch._foreach_copy_(views, [self.params[i].grad for i in idx])
         return self.gflat[lo:hi]
+
+
+class _Moments:
+    """Adam state (moments, step counts) of ONE optimiser over a home's slots, kept beside the home: used when another live
+    optimiser already keeps its state in the home itself.  torch.optim.Adam holds its state per optimiser, and the reference
+    builds two of them over the same policy (Imitation_learning.py:379 and :812): the second must not see, or wipe, the first's."""
+
+    def __init__(self, home: _Home):
+        self.home = weakref.ref(home)
+        self.exp_avg = self.exp_avg_sq = None
+        self.steps = [0] * len(home.params)
+
+    def moments(self):
+        if self.exp_avg is None:
+            flat = self.home().flat
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(flat), torch.zeros_like(flat)
+        return self.exp_avg, self.exp_avg_sq
 
 
 def _layout(module: torch.nn.Module):
@@ -200,11 +223,22 @@ class FlatAdam:
             _Home(loose)               # parameters handed over one by one that no module home owns yet
         self.params = chosen
         self.step_count = 0
-        # Like a new torch.optim.Adam, a new FlatAdam starts from empty state: moments and step counts live with the parameters'
-        # home (they follow the parameters when a home is rebuilt), so whatever an EARLIER optimiser over the same parameters left
-        # there is cleared here.  load_state_dict() restores a saved state.
+        # Like a new torch.optim.Adam, a new FlatAdam starts from empty state.  Moments and step counts normally live with the
+        # parameters' home (they follow the parameters when a home is rebuilt), owned by ONE optimiser per slot.  A slot whose owner
+        # is still alive keeps serving that optimiser -- this one then keeps its own state beside the home (`_Moments`), exactly as
+        # two torch.optim.Adam instances over the same parameters would; a slot whose owner is gone is taken over and whatever it
+        # left there is cleared.  load_state_dict() restores a saved state.
+        self._private = {}                 # id(home) -> _Moments
         for p in chosen:
             home, i = _HOME_OF[p]
+            other = home.owner[i]() if home.owner[i] is not None else None
+            if other is not None and other is not self and id(home) not in self._private:
+                self._private[id(home)] = _Moments(home)
+        for p in chosen:
+            home, i = _HOME_OF[p]
+            if id(home) in self._private:
+                continue
+            home.owner[i] = weakref.ref(self)
             if home.steps[i]:
                 home.steps[i] = 0
                 if home.exp_avg is not None:
@@ -214,6 +248,18 @@ class FlatAdam:
 
     def _all_params(self):
         return self.params
+
+    def _state(self, home: _Home):
+        """where this optimiser's moments / step counts for `home`'s slots live: the home itself, or its own `_Moments`"""
+        if not self._private:
+            return home
+        st = self._private.get(id(home))
+        if st is not None and st.home() is home:
+            return st
+        if any(m.home() is None or not m.home().intact() for m in self._private.values()):
+            raise _lib.DgvitError("FlatAdam: parameter storage was re-homed after this (second) optimiser over the same parameters was "
+                                  "built; rebuild the optimiser")
+        return home
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         for p in self.params:
@@ -236,8 +282,9 @@ class FlatAdam:
         for home, idx in by_home.values():
             idx.sort()
             cur = [idx[0]]
+            steps = self._state(home).steps
             for a, b in zip(idx, idx[1:]):
-                if b == a + 1 and home.steps[b] == home.steps[a] and home.sections[b] == home.sections[a]:
+                if b == a + 1 and steps[b] == steps[a] and home.sections[b] == home.sections[a]:
                     cur.append(b)
                 else:
                     runs.append((home, cur))
@@ -254,20 +301,21 @@ class FlatAdam:
         self.step_count += 1
         step_ptr = ctypes.c_void_p(0)
         if self.capturable:
-            if len({home.steps[idx[0]] for home, idx in runs}) != 1:
+            if len({self._state(home).steps[idx[0]] for home, idx in runs}) != 1:
                 raise _lib.DgvitError("FlatAdam(capturable=True): every parameter must receive a gradient on every step")
             if self._step_dev is None:
-                self._step_dev = torch.full((1,), runs[0][0].steps[runs[0][1][0]], dtype=torch.int64, device=runs[0][0].flat.device)
+                self._step_dev = torch.full((1,), self._state(runs[0][0]).steps[runs[0][1][0]], dtype=torch.int64, device=runs[0][0].flat.device)
             self._step_dev += 1                      # a device op: replayed with the graph
             step_ptr = ctypes.c_void_p(self._step_dev.data_ptr())
         for home, idx in runs:
             lo = home.offsets[idx[0]]
             n = home.offsets[idx[-1]] + _al4(home.params[idx[-1]].numel()) - lo
             g = home.grad_run(idx)
-            m, v = home.moments()
-            t = home.steps[idx[0]] + 1
+            st = self._state(home)
+            m, v = st.moments()
+            t = st.steps[idx[0]] + 1
             for i in idx:
-                home.steps[i] = t
+                st.steps[i] = t
             with torch.cuda.device(home.flat.device):
                 rc = lib.dgvit_adam_step(ctypes.c_void_p(home.flat.data_ptr() + 4 * lo), ctypes.c_void_p(g.data_ptr()),
                                          ctypes.c_void_p(m.data_ptr() + 4 * lo), ctypes.c_void_p(v.data_ptr() + 4 * lo), n,
@@ -293,17 +341,19 @@ class FlatAdam:
             dev_step = int(self._step_dev.item())
             for p in self.params:
                 home, i = _HOME_OF[p]
-                if home.steps[i] > 0:
-                    home.steps[i] = dev_step
+                st = self._state(home)
+                if st.steps[i] > 0:
+                    st.steps[i] = dev_step
             self.step_count = max(self.step_count, dev_step)
         for p in self.params:
             home, i = _HOME_OF[p]
+            st = self._state(home)
             o, n = home.offsets[i], p.numel()
-            if home.exp_avg is None or home.steps[i] == 0:
+            if st.exp_avg is None or st.steps[i] == 0:
                 state.append(None)
             else:
-                state.append({"step": home.steps[i], "exp_avg": home.exp_avg[o:o + n].view_as(p).clone(),
-                              "exp_avg_sq": home.exp_avg_sq[o:o + n].view_as(p).clone()})
+                state.append({"step": st.steps[i], "exp_avg": st.exp_avg[o:o + n].view_as(p).clone(),
+                              "exp_avg_sq": st.exp_avg_sq[o:o + n].view_as(p).clone()})
         return {"step": self.step_count, "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
                 "state": state}
 
@@ -313,18 +363,19 @@ class FlatAdam:
         self.step_count = int(sd["step"])
         for p, st in zip(self.params, sd["state"]):
             home, i = _HOME_OF[p]
+            mine = self._state(home)
             o, n = home.offsets[i], p.numel()
-            m, v = home.moments()
+            m, v = mine.moments()
             if st is None:
-                home.steps[i] = 0
+                mine.steps[i] = 0
                 m[o:o + n].zero_()
                 v[o:o + n].zero_()
             else:
-                home.steps[i] = int(st["step"])
+                mine.steps[i] = int(st["step"])
                 m[o:o + n].view_as(p).copy_(st["exp_avg"])
                 v[o:o + n].view_as(p).copy_(st["exp_avg_sq"])
         if self._step_dev is not None:
-            self._step_dev.fill_(max((_HOME_OF[p][0].steps[_HOME_OF[p][1]] for p in self.params), default=0))
+            self._step_dev.fill_(max((self._state(_HOME_OF[p][0]).steps[_HOME_OF[p][1]] for p in self.params), default=0))
 
 
 def _flat_pair(target, source):

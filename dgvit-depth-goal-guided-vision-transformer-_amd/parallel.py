@@ -27,22 +27,29 @@ class GradSync:
         """``force_collective``: issue the all-reduce even in a world of one rank (a 1-rank RCCL group reduces a buffer onto
         itself) -- lets a single-GPU box exercise the exact code path the 8-GPU run takes.
         ``overlap``: start each transformer block's all-reduce from inside the encoder backward (see the module docstring).
-        Needs ``zero_grad()`` of this class (or ``set_to_none``) before every backward, and one backward per ``sync()``."""
-        self.params: List[torch.nn.Parameter] = []
+        ``zero_grad()`` of this class ARMS the hook and ``sync()`` disarms it: only the backward between the two starts early
+        all-reduces.  Any other backward through the same encoder (DRL.py:407-413: the policy loss is back-propagated through the
+        critic, whose gradients nobody wants) is ignored, so it can neither launch collectives nor leave stale entries behind."""
+        self.params: List[torch.nn.Parameter] = []        # trainable: their gradients are exchanged
+        self.all_params: List[torch.nn.Parameter] = []    # every parameter, frozen ones too: broadcast_parameters sends them all
         self.modules = list(modules)
         self.force_collective = bool(force_collective)
         seen = set()
         for m in self.modules:
             for p in m.parameters():
-                if p.requires_grad and id(p) not in seen:
+                if id(p) not in seen:
                     seen.add(id(p))
-                    self.params.append(p)
+                    self.all_params.append(p)
+                    if p.requires_grad:
+                        self.params.append(p)
         self.group = process_group
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._last_numel = 0
         self.overlap = bool(overlap)
         self._side = {}          # device -> side stream the early all-reduces are queued on
-        self._early = []         # (storage data_ptr, lo, hi, work handle) of this step's early all-reduces
+        self._early = []         # (flat buffer, lo, hi, work handle) of this step's early all-reduces; holding the buffer keeps its address
+        #                          from being handed to another tensor while the entry lives (entries are matched by storage address)
+        self._armed = False      # overlap: set by zero_grad(), cleared by sync() -- backward passes outside that window are ignored
         self.early_launches = 0  # all-reduces started from inside a backward so far (tests, timelines)
         self.on_block_queued = None   # optional callable(side_stream): after each block's all-reduces were queued (tools/overlap_timeline.py)
         if self.overlap:
@@ -64,14 +71,15 @@ class GradSync:
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
     def broadcast_parameters(self, src: int = 0) -> None:
-        """Make every rank start from rank `src`'s weights (DRL.py builds nets from a per-process seed)."""
+        """Make every rank start from rank `src`'s weights (DRL.py builds nets from a per-process seed) -- frozen parameters
+        included: a frozen encoder under a heads-only optimiser (DRL.py:145-148) must be the same network on every rank too."""
         if self.world == 1 and not self.force_collective:
             return
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("GradSync: torch.distributed is not initialised")
         from .optim import _HOME_OF
         done = set()
-        for p in self.params:
+        for p in self.all_params:
             ent = _HOME_OF.get(p)
             if ent is not None and ent[0].intact():          # a flattened network travels as ONE buffer
                 if id(ent[0]) not in done:
@@ -88,6 +96,15 @@ class GradSync:
         accumulate or fill kernel.  Use instead of optimizer.zero_grad()."""
         for p in self.params:
             p.grad = None
+        if self.overlap:
+            self._drop_early()
+            self._armed = True
+
+    def _drop_early(self) -> None:
+        """Early all-reduces nobody collected (a backward that was never followed by sync()): wait for them, then forget them."""
+        stale, self._early = self._early, []
+        for _, _, _, h in stale:
+            h.wait()
 
     def _regions(self):
         """Group live gradients by storage; a group covering one contiguous range is reduced in place."""
@@ -113,21 +130,25 @@ class GradSync:
     def _active(self) -> bool:
         return self.world > 1 or self.force_collective
 
-    def _reduce_op(self):
-        """(op, scale afterwards?): RCCL averages in the collective; gloo only sums"""
-        if dist.get_backend(self.group) == "nccl":
+    def _reduce_op(self, on_device: bool = True):
+        """(op, scale afterwards?) for gradients on the GPU (``on_device``) or on the host: RCCL averages inside the collective, gloo
+        can only sum.  A group with one backend per device type reports e.g. "cpu:gloo,cuda:nccl": the device's entry decides."""
+        backend = str(dist.get_backend(self.group)).lower()
+        per_device = dict(e.split(":", 1) for e in backend.split(",") if ":" in e)
+        mine = per_device.get("cuda" if on_device else "cpu", backend if not per_device else "")
+        if mine == "nccl":
             return dist.ReduceOp.AVG, False
         return dist.ReduceOp.SUM, True
 
     def _on_grads_ready(self, flat, ranges, events) -> None:
         """functional's gradient-ready hook: runs inside the encoder backward, after its kernels were queued.  ``ranges[k]`` of
         ``flat`` is final once ``events[k]`` has happened; its all-reduce goes to the side stream behind that event."""
-        if not self._active():
-            return
+        if not self._active() or not self._armed:
+            return          # not this GradSync's backward (see __init__): nothing is launched, nothing is remembered
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("GradSync: torch.distributed is not initialised")
         key = flat.untyped_storage().data_ptr()
-        if any(e[0] == key for e in self._early):
+        if any(e[0].untyped_storage().data_ptr() == key for e in self._early):
             raise RuntimeError("GradSync(overlap=True): this gradient buffer is already being reduced")
         from . import _lib
         lib = _lib.load()
@@ -135,14 +156,14 @@ class GradSync:
         side = self._side.get(dev)
         if side is None:
             side = self._side[dev] = torch.cuda.Stream(device=dev)
-        op, _ = self._reduce_op()
+        op, _ = self._reduce_op(flat.is_cuda)
         with torch.cuda.device(dev), torch.cuda.stream(side):
             for (lo, hi), ev in zip(ranges, events):
                 _lib.check(lib.dgvit_stream_wait_event(side.cuda_stream, ev), "dgvit_stream_wait_event")
                 for off in range(lo, hi, self.bucket_elems):
                     end = min(hi, off + self.bucket_elems)
                     h = dist.all_reduce(flat[off:end], op=op, group=self.group, async_op=True)   # RCCL's stream waits for `side`
-                    self._early.append((key, off, end, h))
+                    self._early.append((flat, off, end, h))
                     self.early_launches += 1
                 if self.on_block_queued is not None:
                     self.on_block_queued(side)
@@ -151,6 +172,7 @@ class GradSync:
         """All-reduce the gradients to their mean over the ranks; call once after backward.  With ``overlap`` the transformer
         blocks' shares are already on their way (``_on_grads_ready``): only the rest is exchanged here, then the caller's
         stream waits for all of it."""
+        self._armed = False
         shared, loose = self._regions()
         self._last_numel = sum(p.grad.numel() for p in self.params if p.grad is not None)
         if self._last_numel == 0:
@@ -159,8 +181,9 @@ class GradSync:
             return
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("GradSync: torch.distributed is not initialised")
-        op, scale = self._reduce_op()
-        early, self._early = self._early, []
+        some = shared[0] if shared else loose[0]
+        op, scale = self._reduce_op(some.is_cuda)
+        early, self._early = [(f.untyped_storage().data_ptr(), lo, hi, h) for f, lo, hi, h in self._early], []
         live = {g.untyped_storage().data_ptr() for g in shared}
         for key, lo, hi, h in early:
             if key not in live:     # autograd accumulated the new gradients into older .grad tensors: the early reduce missed them
