@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="frames per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=64)
+    ap.add_argument("--cpu-batch", type=int, default=256, help="frames of the 512-frame batch the CPU baseline runs (fwd+bwd, best of 3)")
     ap.add_argument("--no-sac-step", action="store_true", help="skip the secondary full SAC-style step measurement")
     ap.add_argument("--profile-stride", type=int, default=10, help="time every n-th launch of each kernel kind with HIP events (1 = every launch)")
     ap.add_argument("--no-overlap-ab", action="store_true", help="skip the forward-only pass and the helper-stream A/B after the timed region (use when profiling: they launch the same kernels)")
@@ -66,12 +66,12 @@ def cpu_baseline(batch):
     bounded sample: `batch` frames fwd+bwd, best of 3, all host cores."""
     from oracle import dgvit_oracle as O
     cfg = O.GoTConfig(image=IMAGE, patch=PATCH, dim=DIM, depth=DEPTH, heads=HEADS)
-    # a 1-GPU box shares its host: use the cores this process may run on, capped at the 16-core share
+    # BASELINE.md section 4: all host cores of the box (the ones this process may run on), count stated in the result
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))
+    cores = max(1, cores)
     torch.set_num_threads(cores)
     params = O.make_params(O.policy_param_spec(cfg), 3407)
     for v in params.values():
@@ -89,8 +89,8 @@ def cpu_baseline(batch):
         if i > 0:
             best = min(best, dt)
     return {"value": round(batch / best, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/dgvit_oracle.py policy fwd+bwd on {batch} of the 512 frames, train-mode mask, best of 3, "
-                      f"{torch.get_num_threads()} torch threads"}
+            "sample": f"oracle/dgvit_oracle.py policy fwd+bwd on {batch} of the 512 frames, train-mode mask, best of 3 after one warm-up pass, "
+                      f"{torch.get_num_threads()} torch threads = every core this process may run on ({os.cpu_count()} in the machine)"}
 
 
 def sac_step(dgvit_amd, synthetic, B, dev, steps=5):
@@ -245,14 +245,9 @@ def c5_bf16(dgvit_amd, lib, _lib, dev, batch=440, steps=10):
     dtb = (time.perf_counter() - t0) / 5
     train = {"frames_per_s": round(batch / dtb, 1), "ms_per_step": round(dtb * 1e3, 3), "tflops_dense": round(batch / dtb * 3 * fwd / 1e12, 1),
              "frac_of_bf16_peak": round(batch / dtb * 3 * fwd / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
-    c5_traffic, c5_tpath = None, None
-    try:   # bytes that left the L2s per stream-GEMM launch (tools/collect_profiles_c5.sh; FETCH_SIZE x2 + WRITE_SIZE, own --pmc passes)
-        import glob
-        c5_tpath = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c5_bf16_l2_miss_traffic.json")))[-1]
-        with open(c5_tpath) as f:
-            c5_traffic = json.load(f)["kernels"]["gemm_bf16_stream_kernel"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError, IndexError):
-        c5_tpath = None
+    # bytes that left the L2s per stream-GEMM launch (tools/collect_profiles_c5.sh; FETCH_SIZE x2 + WRITE_SIZE, own --pmc passes): quoted from
+    # the newest committed profile, and only while the GEMM kernel sources are the ones it was collected on (synthetic.profile_traffic)
+    c5_traffic, c5_note = synthetic.profile_traffic("r*_c5_bf16_l2_miss_traffic.json", "gemm_bf16_stream_kernel")
     return {"workload": f"C5: GoT 224x224@16x16, L12 H12 D768 M3072 (N=197), forward, batch {batch}, bf16 storage / fp32 accumulate",
             "frames_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "dtype": "bf16",
             "tflops_dense": round(batch / dt * fwd / 1e12, 1), "frac_of_bf16_peak": round(batch / dt * fwd / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
@@ -260,8 +255,8 @@ def c5_bf16(dgvit_amd, lib, _lib, dev, batch=440, steps=10):
                          "unit": "TFLOP/s", "frac": round(gemm_tf / PEAK_BF16_MFMA_TFLOPS, 4),
                          "avg_launch_ms": round(ms[0] / max(1, cnt[0]), 5), "launches_per_step": int(cnt_all[0] // steps),
                          "launches_timed": int(cnt[0]), "traffic": c5_traffic,
-                         "traffic_note": "bytes beyond the L2s per launch at batch 440 (Infinity Cache + HBM; rocprofv3 --pmc FETCH_SIZE(x2) / WRITE_SIZE passes, "
-                                         + (os.path.relpath(c5_tpath, ROOT) if c5_tpath else "not collected") + "); algorithmic operands + outputs: 536 MB per launch on average"},
+                         "traffic_note": "bytes beyond the L2s per launch at batch 440 (Infinity Cache + HBM; rocprofv3 --pmc FETCH_SIZE(x2) / WRITE_SIZE passes): "
+                                         + c5_note + "; algorithmic operands + outputs: 536 MB per launch on average"},
             "gemm_ms_per_step": round(per_step(0), 3), "attn_fwd_ms_per_step": round(per_step(1), 3),
             "norm_ms_per_step": round(per_step(3), 3), "fwd_bwd": train}
 
@@ -317,12 +312,22 @@ def main():
     tgt_mean, tgt_ls = torch.randn(B, 2, generator=g).to(dev), torch.randn(B, 2, generator=g).to(dev)
     torch.manual_seed(1000 + rank)               # decorrelate dropout masks across ranks
 
-    def step():
+    exchange = world > 1 or args.force_collective
+    ar_events = []        # (start, end) HIP events on the compute stream around the gradient exchange of each timed step
+
+    def step(timed=False):
         sync.zero_grad()
         mean, log_std = model([img, pstate])
         loss = torch.nn.functional.mse_loss(mean, tgt_mean) + torch.nn.functional.mse_loss(log_std, tgt_ls)
         loss.backward()
-        sync.sync()
+        if timed and exchange:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            sync.sync()       # (its handles' wait() makes this stream wait for RCCL's: the end event is behind the collectives)
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            sync.sync()
         opt.step()
         return loss
 
@@ -342,7 +347,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = step(timed=True)
     fence()
     dt = time.perf_counter() - t0
     kinds = _lib.PROFILE_KINDS
@@ -355,10 +360,13 @@ def main():
     lib.dgvit_profile_totals(work_all, cnt_all)
     lib.dgvit_profile_sampling(1)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    # the gradient exchange on its own (SURVEY 8(d) "Multi-GPU measurement"): device time between backward's end and the optimiser's start,
+    # max over ranks; algorithm bandwidth = gradient bytes / that time, bus bandwidth = x 2 (n - 1) / n (ring all-reduce traffic per link)
+    ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events)) if ar_events else 0.0
+    tmax = torch.tensor([dt, ar_ms], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = tmax.item()
+    dt, ar_ms = tmax[0].item(), tmax[1].item()
     final_loss = loss.item()
 
     # north-star figure "MFMA roofline fraction of the DGViT forward at batch 512" (N = 1 only, outside the timed region):
@@ -412,14 +420,9 @@ def main():
         def per_step(k):   # sampled average launch duration x launches of that kind per step
             return ms[k] / max(1, cnt[k]) * cnt_all[k] / args.steps
 
-        traffic = None
-        try:   # HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (tools/pmc_traffic.py)
-            import glob
-            tpath = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))[-1]   # the latest round's passes
-            with open(tpath) as f:
-                traffic = json.load(f)["kernels"]["gemm_f32_kernel"]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError, IndexError):
-            tpath = None
+        # HBM bytes per GEMM launch from the rocprofv3 PMC passes of this same command (tools/pmc_traffic.py): the newest committed profile,
+        # null when the GEMM kernel sources have changed since it was collected (a stale file must not ride along with fresh timings)
+        traffic, traffic_note = synthetic.profile_traffic("r*_hbm_traffic.json", "gemm_f32_kernel")
         out = {
             "metric": "depth frames/sec through DGViT fwd+bwd, batch 512x84x84",
             "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -437,7 +440,7 @@ def main():
                                           f"per transformer block from inside the backward ({sync.early_launches // max(1, args.steps + args.warmup)} early all-reduces per step), rest after it")},
             "roofline": {"bound": "mfma", "achieved": round(gemm_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(gemm_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes (" + (os.path.relpath(tpath, ROOT) if tpath else "not collected") + ")",
+                         "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes: " + traffic_note,
                          "kernel": "gemm_f32_kernel (all instantiations: NT fwd, NN dgrad, TN wgrad)",
                          "launches_per_step": int(cnt_all[0] // max(1, args.steps)),
                          "avg_launch_ms": round(ms[0] / max(1, cnt[0]), 5),
@@ -454,6 +457,16 @@ def main():
                            "per_step_note": "isolated launch durations (sampled) x launches per step; back-to-back launches overlap "
                                             "at their edges, so these can add up to more than ms_per_step"},
         }
+        if exchange:
+            nbytes = 4 * sync.grad_numel()
+            algbw = nbytes / (ar_ms * 1e-3) / 1e9 if ar_ms > 0 else None
+            out["allreduce"] = {"ms_per_step": round(ar_ms, 4), "bytes": nbytes, "algbw_GBps": None if algbw is None else round(algbw, 1),
+                                "busbw_GBps": None if algbw is None else round(algbw * 2 * (world - 1) / world, 1),
+                                "share_of_step": round(ar_ms / (dt / args.steps * 1e3), 4),
+                                "note": ("device time of GradSync.sync() on the compute stream (HIP events), max over ranks; with --grad-overlap only the part "
+                                         "that was not hidden under the backward" if args.grad_overlap else
+                                         "device time of GradSync.sync() on the compute stream (HIP events, one exchange after the backward), max over ranks")
+                                        + "; busbw = algbw x 2 (n - 1) / n"}
         if forward_only:
             out["forward_only"] = forward_only
         if overlap_ab:

@@ -4,8 +4,46 @@ Input distributions follow SURVEY.md section 8(d) "Synthetic inputs": frames U[0
 uint8-origin + noise + blur, /255: env_lab.py:295-299,432-433), goal distance U[0,1], heading U[-1,1]
 (env_lab.py:296-297), actions U[-1,1], targets N(0,1); all from numpy.random.RandomState(seed).
 """
+import glob
+import hashlib
+import os
+
 import numpy as np
 import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dgvit-depth-goal-guided-vision-transformer-_amd", "csrc")
+
+
+def kernel_source_digest() -> str:
+    """SHA-256 over the GEMM kernel sources and the headers they include (csrc/gemm*.hip, common.h, bf16.h, knobs.h, small_mma.h).
+    tools/pmc_traffic.py stores it with the HBM-traffic figures it extracts from rocprofv3 counter passes; bench.py quotes such a
+    figure only when the digest still matches, i.e. the bytes were measured on the kernels this run is timing."""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(_CSRC, "gemm*.hip"))) + [os.path.join(_CSRC, n) for n in ("common.h", "bf16.h", "knobs.h", "small_mma.h")]:
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def profile_traffic(pattern: str, kernel: str):
+    """(bytes per launch or None, note) from the newest profiles/<pattern> whose kernel-source digest matches the tree."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    paths = sorted(glob.glob(os.path.join(root, "profiles", pattern)))
+    if not paths:
+        return None, "not collected"
+    path = paths[-1]
+    rel = os.path.relpath(path, root)
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        val = d["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None, f"{rel}: unreadable"
+    commit = d.get("collected_at_commit", "unrecorded")
+    if d.get("kernel_sources_sha256") != kernel_source_digest():
+        return None, (f"{rel} (collected at commit {commit}) was measured on other GEMM kernel sources than this run's: not quoted "
+                      "(re-collect with tools/collect_profiles.sh)")
+    return val, f"from profile {rel}, collected at commit {commit} on the same GEMM kernel sources (sha256 {d['kernel_sources_sha256'][:12]}); not measured by this run"
 
 
 def make_inputs(image, batch, seed):

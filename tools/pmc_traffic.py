@@ -11,7 +11,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from synthetic import kernel_source_digest  # noqa: E402
 
 
 def family(name):
