@@ -161,7 +161,9 @@ def test_two_live_optimisers_over_the_same_parameters_keep_separate_state(amd):
     step([(a, il_a), (b, il_b)])          # ... and the first continues with ITS moments at step 3
     step([(a, rl_a), (b, rl_b)])
     for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
-        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+        # (a wiped or shared state moves a parameter by O(lr) = 1e-3 .. 3e-3; Adam's m / sqrt(v) amplifies fp32 rounding of near-zero
+        #  gradients to a few 1e-5 on a handful of elements, hence the absolute tolerance)
+        np.testing.assert_allclose(pa.detach().cpu().numpy(), pb.detach().cpu().numpy(), rtol=1e-4, atol=1e-4, err_msg=k)
     s1 = [s["step"] for s in il_a.state_dict()["state"] if s is not None]
     s2 = [s["step"] for s in rl_a.state_dict()["state"] if s is not None]
     assert set(s1) == {3} and set(s2) == {2}
