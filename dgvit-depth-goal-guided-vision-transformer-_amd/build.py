@@ -23,7 +23,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libdgvit_hip.so")
 LIB_DIAG = os.path.join(HERE, "libdgvit_hip_diag.so")   # the same sources with -DDGVIT_DIAG: knobs, stamps, experiments (tools/, A/B tests)
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "embed.hip", "conv.hip", "optim.hip", "profile.hip", "preprocess.hip", "gemm_bf16.hip",
-           "gemm_bf16_stream.hip", "attention_bf16.hip", "misc_bf16.hip", "heads.hip", "dgvit_api.hip"]
+           "gemm_bf16_stream.hip", "attention_bf16.hip", "misc_bf16.hip", "heads.hip", "block.hip", "dgvit_api.hip"]
 DIAG_ONLY_SOURCES = ["frame.hip"]    # experiments that are not part of the product library
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "kernels.h"), os.path.join(CSRC, "bf16.h"), os.path.join(CSRC, "small_mma.h"),
            os.path.join(CSRC, "knobs.h"), os.path.join(INCLUDE, "dgvit_hip.h"), os.path.join(INCLUDE, "dgvit_hip_diag.h")]

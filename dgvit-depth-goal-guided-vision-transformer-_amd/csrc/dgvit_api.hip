@@ -17,7 +17,7 @@ int g_gemm_tile_hint = 0, g_gemm_split = 1, g_gemm_lds_pad = 0, g_gemm_persist =
 long long* g_gemm_stamps = nullptr;
 int g_gemm_stamp_capacity = 0;
 long long g_gemm_persist_launches = 0;
-int g_group_reduce = 1, g_ln_fusion = 1, g_conv_gather = 1, g_small_path = 0, g_small_path_max_rows = 4160;
+int g_group_reduce = 1, g_ln_fusion = 1, g_conv_gather = 1, g_small_path = 0, g_small_path_max_rows = 4160, g_block_path = 1, g_block_path_max_rows = 4160;
 int g_gemm_bf16_tile_hint = 0, g_gemm_bf16_m16 = 1, g_gemm_bf16_group_m = 8, g_attn_bwd64 = 1, g_gemm_bf16_l2_budget_kb = 2048;
 long long* g_gemm_bf16_stamps = nullptr;
 #endif
@@ -214,9 +214,15 @@ SplitNeed backward_split_need(const Dims& d) {
 struct Ws {
   long long patches, x0, pooled, layer0, layer_stride, layer_floats, total;
   long long sk_counters, sk_slabs, sk_ncounters, sk_slab_floats;   // in-launch split-K scratch (0 floats when no GEMM splits)
+  long long bp_counters, bp_slabs, bp_ncounters;                    // combine scratch of the two-launch small-batch blocks (block.hip; inference only)
   // per-layer offsets relative to the layer base
   long long mean1, rstd1, ln1, qkv, ao, lse, xmid, mean2, rstd2, ln2, h1, a1, xout;
 };
+
+// no-grad forwards of a few frames take the two-launch blocks of block.hip (the size bound is the only part a diagnostic knob can move)
+bool block_path_eligible(const Dims& d) {
+  return d.proj && d.T <= (long long)(g_block_path_max_rows > 4160 ? g_block_path_max_rows : 4160) && block_path_supports(d.B, d.N, d.D, d.H, d.dh, d.M);
+}
 
 Ws make_ws(const Dims& d, int save) {
   Ws w;
@@ -228,6 +234,12 @@ Ws make_ws(const Dims& d, int save) {
   w.sk_ncounters = sn.tiles; w.sk_slab_floats = sn.slab;
   w.sk_counters = o; o += al4(sn.tiles);
   w.sk_slabs = o; o += al4(sn.slab);
+  w.bp_counters = w.bp_slabs = o; w.bp_ncounters = 0;
+  if (!save && block_path_eligible(d)) {
+    w.bp_ncounters = block_path_counters(d.B, d.N);
+    w.bp_counters = o; o += al4(w.bp_ncounters);
+    w.bp_slabs = o; o += al4(block_path_slab_floats(d.B, d.N, d.D, d.H, d.M));
+  }
   long long l = 0;
   w.mean1 = l; l += al4(d.T);
   w.rstd1 = l; l += al4(d.T);
@@ -292,6 +304,10 @@ extern "C" void dgvit_set_gemm_lds_pad(int bytes) { g_gemm_lds_pad = bytes > 0 ?
 extern "C" void dgvit_set_small_batch_path(int on, int max_rows) {
   g_small_path = on ? 1 : 0;
   if (max_rows > 0) g_small_path_max_rows = max_rows;
+}
+extern "C" void dgvit_set_block_path(int on, int max_rows) {
+  g_block_path = on ? 1 : 0;
+  g_block_path_max_rows = max_rows > 0 ? max_rows : 4160;
 }
 extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = tile; }
 extern "C" void dgvit_set_gemm_bf16_mfma16(int on) { g_gemm_bf16_m16 = on ? 1 : 0; }
@@ -421,8 +437,30 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     return frame_path_forward(x, params, d.L, ws + w.layer0, feat, d.B, d.N, d.D, d.H, d.dh, d.M, st);
 #endif
 
+  // Small no-grad batches (SAC.choose_action on one frame, the target passes of learn() at batch 32): two launches per block, the
+  // sums over heads / hidden chunks taken inside the launches (block.hip), the LayerNorms in their combine steps.
+  const bool use_blocks = !save && g_block_path && w.bp_ncounters > 0 && d.T <= g_block_path_max_rows;
+  if (use_blocks) {
+    int* counters = reinterpret_cast<int*>(ws + w.bp_counters);
+    HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * w.bp_ncounters, st));       // every combine leaves them zero again
+    float* lb = ws + w.layer0;
+    TRY(layernorm_fwd(x, params[P_L0 + L_LN1W], params[P_L0 + L_LN1B], lb + w.ln1, lb + w.mean1, lb + w.rstd1, T, d.D, 1e-5f, 1, st));
+    for (int i = 0; i < d.L; ++i) {
+      const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
+      float* xo = !(i & 1) ? lb + w.xout : ws + w.layer0 + w.layer_floats;
+      const bool last = !dense_last_block(cfg) && !d.pool_mean && i == d.L - 1;
+      const float* next_ln[2] = {nullptr, nullptr};
+      if (i + 1 < d.L) {
+        next_ln[0] = params[P_L0 + DGVIT_PARAMS_PER_LAYER * (i + 1) + L_LN1W];
+        next_ln[1] = params[P_L0 + DGVIT_PARAMS_PER_LAYER * (i + 1) + L_LN1B];
+      }
+      TRY(block_path_layer(x, lb + w.ln1, lb + w.xmid, lb + w.ln2, xo, lp, i + 1 < d.L ? next_ln : nullptr, last ? 1 : 0, ws + w.bp_slabs, counters,
+                           d.B, d.N, d.D, d.H, d.dh, d.M, st));
+      x = xo;
+    }
+  }
   const bool ln_fused = g_ln_fusion && d.D == 64 && g_gemm_tile_hint == 0;   // (the automatic tile for N = 64 is 64 wide)
-  for (int i = 0; i < d.L; ++i) {
+  for (int i = 0; i < d.L && !use_blocks; ++i) {
     const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
     float* lb = ws + w.layer0 + w.layer_stride * i;
     float* xo = (save || !(i & 1)) ? lb + w.xout : ws + w.layer0 + w.layer_floats;

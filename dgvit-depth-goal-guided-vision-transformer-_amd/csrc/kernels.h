@@ -42,6 +42,12 @@ int tanh_gaussian_forward(const float*, const float*, const float*, const float*
                           int, int, hipStream_t);
 int tanh_gaussian_backward(const float*, const float*, const float*, const float*, int, float, float, const float*, const float*,
                            const float*, float*, float*, int, int, hipStream_t);
+// block.hip: two launches per transformer block for small batches (no-grad forward), cross-workgroup sums inside the launches
+bool block_path_supports(int B, int N, int D, int H, int dh, int M);
+long long block_path_slab_floats(int B, int N, int D, int H, int M);
+long long block_path_counters(int B, int N);
+int block_path_layer(const float* x, float* ln1, float* xmid, float* ln2, float* xout, const float* const* lp, const float* const* next_ln,
+                     int token0_only, float* slabs, int* counters, int B, int N, int D, int H, int dh, int M, hipStream_t st);
 // (frame.hip: diagnostic build only)
 bool frame_path_supports(int B, int N, int D, int H, int dh, int M);
 long long frame_path_scratch_floats(int B, int N, int D, int H, int M);

@@ -173,3 +173,110 @@ def test_two_live_optimisers_over_the_same_parameters_keep_separate_state(amd):
     gc.collect()
     c = FlatAdam(a, lr=1e-3)
     assert not c._private and all(s is None for s in c.state_dict()["state"])
+
+
+# ------------------------------------------------------------------------------------------------ two launches per block (block.hip)
+from helpers import knobs  # noqa: E402
+
+
+def _block_path(on):
+    """ON is the product's default for no-grad forwards of at most 4160 token rows; OFF (the seven-launch GEMM schedule) exists in the
+    diagnostic library only"""
+    return knobs(block_path=(1 if on else 0, 4160))
+
+
+@pytest.mark.parametrize("name,cls", [("policy_native_shipped", "policy"), ("policy_native_small", "policy"), ("policy_c2", "policy"),
+                                      ("detpolicy_native_shipped", "det"), ("policy_native_h1", "policy")])
+def test_block_path_matches_reference_goldens(amd, name, cls):
+    """no_grad forward (what SAC.choose_action runs, DRL.py:170-185) through the product library: fixtures from the reference's own
+    classes within 1e-4.  policy_native_small (N = 65 at D = 256) exceeds the LDS budget of the fused kernels and policy_native_h1 has
+    no output projection: both must fall through to the GEMM schedule without a trace."""
+    fx = load_fixture(name)
+    cfg = fixture_cfg(fx)
+    batch, seed = int(fx["meta/batch"]), int(fx["meta/seed"])
+    kw = dict(image_size=cfg.image, patch_size=cfg.patch)
+    if cls == "policy":
+        m = amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, **kw)
+        m.load_state_dict(O.make_params(O.policy_param_spec(cfg), seed), strict=True)
+    else:
+        m = amd.DeterministicGoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, **kw)
+        m.load_state_dict(O.make_params(O.detpolicy_param_spec(cfg), seed), strict=True)
+    m = m.eval().to("cuda")
+    img, pstate, _, _ = O.make_inputs(cfg, batch, seed)
+    with torch.no_grad():
+        out = m([img.cuda(), pstate.cuda()])
+    if cls == "policy":
+        np.testing.assert_allclose(out[0].cpu().numpy(), fx["mean"], rtol=0, atol=OUT_TOL)
+        np.testing.assert_allclose(out[1].cpu().numpy(), fx["log_std"], rtol=0, atol=OUT_TOL)
+    else:
+        np.testing.assert_allclose(out.cpu().numpy(), fx["mean"], rtol=0, atol=OUT_TOL)
+
+
+@pytest.mark.parametrize("image,patch,dim,depth,heads,dim_head,B,pool", [
+    ((128, 160), (16, 20), 64, 4, 4, 64, 1, "cls"), ((128, 160), (16, 20), 64, 4, 4, 64, 2, "cls"), ((128, 160), (16, 20), 64, 4, 4, 64, 32, "cls"),
+    ((128, 160), (16, 20), 64, 2, 4, 64, 64, "cls"),  # 4160 rows: the largest batch the path takes
+    ((128, 160), (16, 20), 64, 2, 4, 64, 65, "cls"),  # one frame more: the GEMM schedule
+    ((84, 84), (12, 12), 256, 3, 8, 64, 3, "cls"),    # DGViT-small width, N = 50 (two key tiles)
+    ((84, 84), (12, 12), 256, 2, 8, 64, 33, "cls"),   # ... 1650 rows: 52 row tiles, the last one ragged
+    ((84, 84), (14, 14), 128, 2, 3, 32, 5, "cls"),    # N = 37, dim_head 32, three heads
+    ((84, 84), (14, 14), 96, 2, 3, 32, 5, "cls"),     # D = 96: not a power of two -> GEMM schedule
+    ((84, 84), (7, 7), 64, 1, 2, 64, 2, "cls"),       # N = 145 > 128: not eligible
+    ((96, 96), (12, 12), 64, 2, 2, 64, 3, "cls"),     # N = 65 exactly three key tiles with ONE real key in the last
+    ((60, 96), (12, 12), 32, 2, 1, 64, 4, "cls"),     # N = 41, D = 32 (four k-slices in the output stages), one head of 64
+    ((24, 24), (24, 24), 32, 2, 2, 32, 4, "cls"),     # N = 2
+    ((84, 84), (12, 12), 64, 3, 4, 64, 6, "mean"),    # pool = 'mean': every row of the last block is needed (dense)
+])
+def test_block_path_equals_gemm_schedule(amd, image, patch, dim, depth, heads, dim_head, B, pool):
+    """Same module, same inputs, eval and train mode (same dropout seed): the two-launch blocks and the seven-launch GEMM schedule agree
+    to fp32 summation-order rounding, both with the oracle (1e-4), and the fused path is bit-reproducible."""
+    cfg = O.GoTConfig(image=image, patch=patch, dim=dim, depth=depth, heads=heads, dim_head=dim_head, mlp_dim=256 if dim < 64 else 2048)
+    params = O.make_params(O.got_param_spec(cfg, prefix=""), 17)
+    m = amd.GoT(image_size=image, patch_size=patch, num_classes=2, dim=dim, depth=depth, heads=heads, mlp_dim=cfg.mlp_dim, channels=1,
+                dim_head=dim_head, pool=pool)
+    m.load_state_dict(params, strict=True)
+    m = m.cuda()
+    img, _, _, _ = O.make_inputs(cfg, B, 17)
+    goal = torch.randn(B, dim, generator=torch.Generator().manual_seed(3))
+    ref = O.got_forward(params, img, goal, cfg, prefix="", pool=pool)
+    outs = {}
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        for on in (True, False):
+            with _block_path(on):
+                torch.manual_seed(5)      # same dropout seed draw for both paths
+                with torch.no_grad():
+                    outs[(mode, on)] = m(img.cuda(), goal.cuda()).cpu()
+        np.testing.assert_allclose(outs[(mode, True)].numpy(), outs[(mode, False)].numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(outs[("eval", True)].numpy(), ref.detach().numpy(), rtol=0, atol=OUT_TOL)
+    assert (outs[("train", True)] - outs[("eval", True)]).abs().max().item() > 1e-3      # dropout was live in train mode
+    m.eval()
+    with torch.no_grad():
+        again = m(img.cuda(), goal.cuda()).cpu()
+    assert torch.equal(again, outs[("eval", True)]), "the in-launch combines must sum in a fixed order"
+    # the dense last block (A/B flag) through the fused kernels too
+    m.set_schedule(dense_last_block=True)
+    with torch.no_grad():
+        dense = m(img.cuda(), goal.cuda()).cpu()
+    np.testing.assert_allclose(dense.numpy(), outs[("eval", True)].numpy(), rtol=0, atol=2e-5)
+
+
+def test_block_path_runs_two_launches_per_block(amd):
+    """The product library takes the fused kernels for a single frame (profile counters of kind 'other': 1 LayerNorm + 2 per block
+    + patch/goal/final kernels) and the GEMM kind sees only the patch embedding."""
+    import ctypes
+    from dgvit_amd import _lib
+    lib = amd.load_library()
+    m = amd.GoTPolicy(2, 2, 4, 4, 64).to("cuda").eval()
+    img, ps = torch.rand(1, 128, 160, device="cuda"), torch.rand(1, 2, device="cuda")
+    with torch.no_grad():
+        m([img, ps])
+        torch.cuda.synchronize()
+        lib.dgvit_profile_sampling(1)
+        lib.dgvit_profile_start(256)
+        m.trans(img, torch.zeros(1, 64, device="cuda"))
+        torch.cuda.synchronize()
+    kinds = _lib.PROFILE_KINDS
+    ms, work, cnt = (ctypes.c_double * kinds)(), (ctypes.c_double * kinds)(), (ctypes.c_longlong * kinds)()
+    lib.dgvit_profile_stop(ms, work, cnt)
+    assert cnt[0] == 1, f"{cnt[0]} GEMM launches in a single-frame encoder forward (expected the patch embedding only)"
+    assert cnt[1] == 0 and cnt[2] == 0
