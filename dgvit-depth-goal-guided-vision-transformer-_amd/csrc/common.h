@@ -53,7 +53,10 @@ enum GemmEpilogue {
   EPI_DGELU = 2,   // C = acc * gelu'(aux[m][n])
   EPI_RELU = 3,    // C = max(acc + bias, 0)
   EPI_DRELU = 4,   // C = aux[m][n] > 0 ? acc : 0
-  EPI_SPLITK = 5   // C = slab[z][m][n] = acc   (reduced later by dgvit_reduce_slabs)
+  EPI_SPLITK = 5,  // C = slab[z][m][n] = acc   (reduced later by dgvit_reduce_slabs)
+  EPI_GELU2D = 6,  // t = acc + bias ; C = gelu_erf'(t) ; C2 = gelu_erf(t)        (training forward of fc1: the factor the backward needs)
+  EPI_DMUL = 7,    // C = acc * aux[m][n]                                          (its data gradient: dh = (dy W2) * gelu'(h), factor stored)
+  EPI_GELU = 8     // C = gelu_erf(acc + bias)                                     (no-grad forward of fc1: the pre-activation is never stored)
 };
 
 struct GemmParams {
@@ -147,6 +150,13 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + fast_erf(x * 0.70710678118654752440f));
   const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
   return fmaf(x, pdf, cdf);
+}
+
+// gelu and its derivative together: the erf form's exp(-x^2 / 2) is the density's, so the derivative costs two more FMAs.  The two
+// results are bit-identical to gelu_erf / gelu_erf_grad (same operations in the same order).
+__device__ __forceinline__ void gelu_erf_both(float x, float& gelu, float& grad) {
+  gelu = gelu_erf(x);
+  grad = gelu_erf_grad(x);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -20,6 +20,7 @@ long long g_gemm_persist_launches = 0;
 int g_group_reduce = 1, g_ln_fusion = 1, g_conv_gather = 1, g_small_path = 0, g_small_path_max_rows = 4160, g_block_path = 1, g_block_path_max_rows = 4160;
 int g_gemm_bf16_tile_hint = 0, g_gemm_bf16_m16 = 1, g_gemm_bf16_group_m = 8, g_attn_bwd64 = 1, g_gemm_bf16_l2_budget_kb = 2048;
 long long* g_gemm_bf16_stamps = nullptr;
+long long* g_block_stamps = nullptr;
 #endif
 static inline bool dense_last_block(const dgvit_config* c) { return (c->flags & DGVIT_FLAG_DENSE_LAST_BLOCK) != 0; }
 static inline bool wgrad_overlap(const dgvit_config* c) { return (c->flags & DGVIT_FLAG_WGRAD_OVERLAP) != 0; }
@@ -219,9 +220,16 @@ struct Ws {
   long long mean1, rstd1, ln1, qkv, ao, lse, xmid, mean2, rstd2, ln2, h1, a1, xout;
 };
 
-// no-grad forwards of a few frames take the two-launch blocks of block.hip (the size bound is the only part a diagnostic knob can move)
+// no-grad forwards of a few frames take the two-launch blocks of block.hip.  Where they win, measured against the seven-launch GEMM
+// schedule as captured single-launch graphs of policy.sample() (tools/small_batch_ab.py, profiles/r04_*_small_batch_ab.txt): while the
+// attention kernel's workgroups (frames x heads x query tiles) fit the chip one per CU -- 0.68-0.76 of the GEMM schedule's time at D = 64
+// for 1-16 frames, 0.75-0.89 at D = 128 for 1-32 frames; parity at 32 frames of the shipped model, slower beyond -- and, at D = 256, where
+// a workgroup's projections (contraction over 256 on ONE CU) outweigh the saved launches, for a single frame only (0.95; 1.1-1.5 beyond).
 bool block_path_eligible(const Dims& d) {
-  return d.proj && d.T <= (long long)(g_block_path_max_rows > 4160 ? g_block_path_max_rows : 4160) && block_path_supports(d.B, d.N, d.D, d.H, d.dh, d.M);
+  if (!d.proj || d.T > g_block_path_max_rows || !block_path_supports(d.B, d.N, d.D, d.H, d.dh, d.M)) return false;
+  KNOB_IF(g_block_path == 2) return true;      // diagnostic build: every supported shape (tests of ragged row tiles, many frames)
+  const long long items = (long long)d.B * d.H * ((d.N + 31) / 32);
+  return d.D <= 128 ? items <= 256 : items <= 16;
 }
 
 Ws make_ws(const Dims& d, int save) {
@@ -233,13 +241,16 @@ Ws make_ws(const Dims& d, int save) {
   const SplitNeed sn = forward_split_need(d);
   w.sk_ncounters = sn.tiles; w.sk_slab_floats = sn.slab;
   w.sk_counters = o; o += al4(sn.tiles);
-  w.sk_slabs = o; o += al4(sn.slab);
-  w.bp_counters = w.bp_slabs = o; w.bp_ncounters = 0;
-  if (!save && block_path_eligible(d)) {
+  // (the small-batch blocks' arrival counters sit right behind the split-K ones: ONE memset zeroes both)
+  w.bp_counters = o; w.bp_ncounters = 0;
+  const bool blocks = !save && block_path_eligible(d);
+  if (blocks) {
     w.bp_ncounters = block_path_counters(d.B, d.N);
-    w.bp_counters = o; o += al4(w.bp_ncounters);
-    w.bp_slabs = o; o += al4(block_path_slab_floats(d.B, d.N, d.D, d.H, d.M));
+    o += al4(w.bp_ncounters);
   }
+  w.sk_slabs = o; o += al4(sn.slab);
+  w.bp_slabs = o;
+  if (blocks) o += al4(block_path_slab_floats(d.B, d.N, d.D, d.H, d.M));
   long long l = 0;
   w.mean1 = l; l += al4(d.T);
   w.rstd1 = l; l += al4(d.T);
@@ -306,9 +317,10 @@ extern "C" void dgvit_set_small_batch_path(int on, int max_rows) {
   if (max_rows > 0) g_small_path_max_rows = max_rows;
 }
 extern "C" void dgvit_set_block_path(int on, int max_rows) {
-  g_block_path = on ? 1 : 0;
+  g_block_path = on < 0 ? 0 : (on > 2 ? 2 : on);
   g_block_path_max_rows = max_rows > 0 ? max_rows : 4160;
 }
+extern "C" void dgvit_set_block_stamps(long long* stamps) { g_block_stamps = stamps; }
 extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = tile; }
 extern "C" void dgvit_set_gemm_bf16_mfma16(int on) { g_gemm_bf16_m16 = on ? 1 : 0; }
 extern "C" void dgvit_set_attention_bwd_single_pass(int on) { g_attn_bwd64 = on ? 1 : 0; }
@@ -403,8 +415,10 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
   if (w.sk_slab_floats > 0) {
     sk.counters = reinterpret_cast<int*>(ws + w.sk_counters); sk.ncounters = (int)w.sk_ncounters;
     sk.slabs = ws + w.sk_slabs; sk.slab_cap = w.sk_slab_floats;
-    HIP_TRY(hipMemsetAsync(sk.counters, 0, sizeof(int) * w.sk_ncounters, st));   // every split GEMM leaves them zero again
   }
+  // arrival counters of the split GEMMs and of the small-batch blocks (adjacent): every user leaves them zero again
+  if (w.sk_slab_floats > 0 || w.bp_ncounters > 0)
+    HIP_TRY(hipMemsetAsync(ws + w.sk_counters, 0, sizeof(int) * (w.bp_counters - w.sk_counters + w.bp_ncounters), st));
   // patch embedding (GoalFormer.py:137-139,157) + goal token, positional embedding, dropout (:160-163)
   float* patches = ws + w.patches;
   float* x = ws + w.x0;
@@ -439,12 +453,10 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
 
   // Small no-grad batches (SAC.choose_action on one frame, the target passes of learn() at batch 32): two launches per block, the
   // sums over heads / hidden chunks taken inside the launches (block.hip), the LayerNorms in their combine steps.
-  const bool use_blocks = !save && g_block_path && w.bp_ncounters > 0 && d.T <= g_block_path_max_rows;
+  const bool use_blocks = !save && g_block_path && w.bp_ncounters > 0;
   if (use_blocks) {
-    int* counters = reinterpret_cast<int*>(ws + w.bp_counters);
-    HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int) * w.bp_ncounters, st));       // every combine leaves them zero again
+    int* counters = reinterpret_cast<int*>(ws + w.bp_counters);       // (zeroed with the split-K counters above)
     float* lb = ws + w.layer0;
-    TRY(layernorm_fwd(x, params[P_L0 + L_LN1W], params[P_L0 + L_LN1B], lb + w.ln1, lb + w.mean1, lb + w.rstd1, T, d.D, 1e-5f, 1, st));
     for (int i = 0; i < d.L; ++i) {
       const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
       float* xo = !(i & 1) ? lb + w.xout : ws + w.layer0 + w.layer_floats;
@@ -454,8 +466,9 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
         next_ln[0] = params[P_L0 + DGVIT_PARAMS_PER_LAYER * (i + 1) + L_LN1W];
         next_ln[1] = params[P_L0 + DGVIT_PARAMS_PER_LAYER * (i + 1) + L_LN1B];
       }
-      TRY(block_path_layer(x, lb + w.ln1, lb + w.xmid, lb + w.ln2, xo, lp, i + 1 < d.L ? next_ln : nullptr, last ? 1 : 0, ws + w.bp_slabs, counters,
-                           d.B, d.N, d.D, d.H, d.dh, d.M, st));
+      // (block 0 normalises its input inside the attention kernel; later blocks read the rows the previous MLP kernel normalised)
+      TRY(block_path_layer(x, i == 0 ? nullptr : lb + w.ln1, xo, lb + w.ln1, lp, i + 1 < d.L ? next_ln : nullptr, last ? 1 : 0, ws + w.bp_slabs,
+                           counters, d.B, d.N, d.D, d.H, d.dh, d.M, st));
       x = xo;
     }
   }
@@ -504,10 +517,14 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     // x = ff(LN(x)) + x     (GoalFormer.py:104, 42-50)
     if (!ln_fused || !d.proj) TRY(layernorm_fwd(lb + w.xmid, lp[L_LN2W], lp[L_LN2B], lb + w.ln2, lb + w.mean2, lb + w.rstd2, tok, d.D, 1e-5f, rs, st));
     {
-      GemmParams p = gp(lb + w.ln2, rs * d.D, lp[L_FC1W], d.D, lb + w.h1, d.M, tok, d.M, d.D);   // h1 / a1 are dense (tok, M)
-      p.bias = lp[L_FC1B]; p.C2 = lb + w.a1; p.ldc2 = d.M;
+      // training: a1 = gelu(t) for fc2 and the weight gradient, and -- in the h1 slot -- gelu'(t), the factor the data gradient of fc2
+      // multiplies by (the erf form already holds its exponential; the backward epilogue then evaluates nothing).  No-grad passes
+      // store a1 only: the pre-activation (210 MB per layer at C3) is never written.
+      GemmParams p = gp(lb + w.ln2, rs * d.D, lp[L_FC1W], d.D, save ? lb + w.h1 : lb + w.a1, d.M, tok, d.M, d.D);   // h1 / a1 are dense (tok, M)
+      p.bias = lp[L_FC1B];
+      if (save) { p.C2 = lb + w.a1; p.ldc2 = d.M; }
       sk.attach(p);
-      TRY(gemm_f32(GEMM_NT, EPI_GELU2, p, 1, st));
+      TRY(gemm_f32(GEMM_NT, save ? EPI_GELU2D : EPI_GELU, p, 1, st));
     }
     {
       GemmParams p = gp(lb + w.a1, d.M, lp[L_FC2W], d.M, xo, rs * d.D, tok, d.D, d.M);
@@ -642,9 +659,9 @@ extern "C" int dgvit_got_backward_ev(const dgvit_config* cfg, const float* const
     TRY(wgrad(dx, rs * d.D, lb + w.a1, d.M, lg[L_FC2W], lg[L_FC2B], d.D, d.M, tok, slabs + s.sl_fc2, s.n_fc2, sw, gq));
     {
       GemmParams p = gp(dx, rs * d.D, lp[L_FC2W], d.M, dh1, d.M, tok, d.M, d.D);
-      p.aux = lb + w.h1; p.ldaux = d.M;
+      p.aux = lb + w.h1; p.ldaux = d.M;             // (the h1 slot holds gelu'(pre-activation), written by the forward)
       sk.attach(p);
-      TRY(gemm_f32(GEMM_NN, EPI_DGELU, p, 1, st));  // dh1 = (dx W2) * gelu'(h1)   [previous layer's wgrads joined below]
+      TRY(gemm_f32(GEMM_NN, EPI_DMUL, p, 1, st));   // dh1 = (dx W2) * gelu'(h1)   [previous layer's wgrads joined below]
     }
     TRY(fork());
     TRY(wgrad(dh1, d.M, lb + w.ln2, rs * d.D, lg[L_FC1W], lg[L_FC1B], d.M, d.D, tok, slabs + s.sl_fc1, s.n_fc1, sw, gq));

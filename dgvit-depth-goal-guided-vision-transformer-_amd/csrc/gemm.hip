@@ -291,6 +291,11 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NT;
   constexpr bool AKC = LAYOUT != GEMM_TN;
   constexpr bool BKC = LAYOUT == GEMM_NT;
+  // EPI_GELU2D / EPI_DMUL: the training forward stores gelu'(pre-activation) INSTEAD of the pre-activation (C) beside gelu (C2) -- the
+  // erf form already holds exp(-x^2 / 2), the derivative costs two more FMAs there -- and the data-gradient GEMM multiplies by that
+  // stored factor instead of evaluating erf and exp per element in its epilogue (same values, bit for bit)
+  constexpr bool TWO_OUT = EPI == EPI_GELU2 || EPI == EPI_GELU2D;
+  constexpr bool ACT_GRAD = EPI == EPI_DGELU || EPI == EPI_DMUL;
   constexpr int WM = BM / T::WVM, WN = BN / T::WVN, TM = WM / 32, TN = WN / 32;
   static_assert(WM % 32 == 0 && WN % 32 == 0 && BM <= NT, "bad wave layout");
   constexpr int A_TILE = AKC ? BM * (BK + 4) : BK * (BM + 4);
@@ -358,7 +363,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   // several thousand cycles under load, paid by every tile.
   // which epilogue (uniform over the launch except for split tiles): see "direct epilogue" below
   constexpr bool DIRECT_OK = LAYOUT != GEMM_TN && VEC == 4 && !GATHER && EPI != EPI_SPLITK && (BKC || TN <= 2);
-  const bool direct = DIRECT_OK && nz == 1 && evec && p.c_rgrp == 0 && p.res_mod == 0 && (EPI != EPI_GELU2 || p.ldc2 == p.ldc) && !DIAG_BIT(p, 8) &&
+  const bool direct = DIRECT_OK && nz == 1 && evec && p.c_rgrp == 0 && p.res_mod == 0 && (!TWO_OUT || p.ldc2 == p.ldc) && !DIAG_BIT(p, 8) &&
                       !(LN_OK && p.ln_y);   // (the fused LayerNorm reduces over the 16 lanes that hold a row of the LDS image)
   int dcol[TN];     // direct epilogue: this lane's column(s) inside the tile
   float dbias[TN];
@@ -368,7 +373,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
     dbias[j] = 0.f;
   }
   float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-  if ((EPI == EPI_STORE || EPI == EPI_GELU2 || EPI == EPI_RELU) && p.bias) {
+  if ((EPI == EPI_STORE || TWO_OUT || EPI == EPI_RELU || EPI == EPI_GELU) && p.bias) {
     if (direct) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) dbias[j] = p.bias[min(n0 + dcol[j], p.N - 1)];
@@ -520,7 +525,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
         const unsigned rowpart = (unsigned)((wm * WM + i * 32 + (r & 3) + 8 * (r >> 2)) * ld * 4);   // uniform
         return n0 + dcol[j] < p.N ? rowpart + (unsigned)((4 * h * ld + dcol[j]) * 4) : DGVIT_OOB;
       };
-      constexpr bool HAS_SIDE = EPI == EPI_STORE || EPI == EPI_DGELU || EPI == EPI_DRELU;
+      constexpr bool HAS_SIDE = EPI == EPI_STORE || ACT_GRAD || EPI == EPI_DRELU;
       const bool use_side = HAS_SIDE && (EPI == EPI_STORE ? p.res != nullptr : true);
       if (HAS_SIDE && use_side) {
         const float* sb = EPI == EPI_STORE ? p.res : p.aux;
@@ -554,12 +559,13 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
               const float sv = side[i][r][j];
               if (EPI == EPI_STORE) acc[i][j][r] += sv;                     // residual first, bias below: the order of the LDS path
               else if (EPI == EPI_DGELU) acc[i][j][r] *= gelu_erf_grad(sv);
+              else if (EPI == EPI_DMUL) acc[i][j][r] *= sv;
               else acc[i][j][r] = sv > 0.f ? acc[i][j][r] : 0.f;
             }
       }
       const __amdgpu_buffer_rsrc_t cr = tile_rsrc(p.C, p.ldc);
       __amdgpu_buffer_rsrc_t c2r = cr;
-      if (EPI == EPI_GELU2) c2r = tile_rsrc(p.C2, p.ldc2);
+      if (TWO_OUT) c2r = tile_rsrc(p.C2, p.ldc2);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -568,18 +574,38 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             v[j] = acc[i][j][r];
-            if (EPI == EPI_STORE || EPI == EPI_GELU2) v[j] += dbias[j];
+            if (EPI == EPI_STORE || TWO_OUT) v[j] += dbias[j];
             else if (EPI == EPI_RELU) v[j] = fmaxf(v[j] + dbias[j], 0.f);
+            else if (EPI == EPI_GELU) v[j] = gelu_erf(v[j] + dbias[j]);
           }
           if constexpr (CW == 1) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), cr, eoff(i, j, r, p.ldc), 0, 0);
-              if (EPI == EPI_GELU2)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gelu_erf(v[j])), c2r, eoff(i, j, r, p.ldc), 0, 0);
+              if constexpr (EPI == EPI_GELU2D) {
+                float gl, gd;
+                gelu_erf_both(v[j], gl, gd);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gd), cr, eoff(i, j, r, p.ldc), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gl), c2r, eoff(i, j, r, p.ldc), 0, 0);
+              } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), cr, eoff(i, j, r, p.ldc), 0, 0);
+                if (EPI == EPI_GELU2)
+                  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gelu_erf(v[j])), c2r, eoff(i, j, r, p.ldc), 0, 0);
+              }
             }
           } else {
             u32x2 w;
+            if constexpr (EPI == EPI_GELU2D) {
+              float gl0, gd0, gl1, gd1;
+              gelu_erf_both(v[0], gl0, gd0);
+              gelu_erf_both(v[1], gl1, gd1);
+              w[0] = __builtin_bit_cast(unsigned, gd0);
+              w[1] = __builtin_bit_cast(unsigned, gd1);
+              __builtin_amdgcn_raw_buffer_store_b64(w, cr, eoff(i, 0, r, p.ldc), 0, 0);
+              w[0] = __builtin_bit_cast(unsigned, gl0);
+              w[1] = __builtin_bit_cast(unsigned, gl1);
+              __builtin_amdgcn_raw_buffer_store_b64(w, c2r, eoff(i, 0, r, p.ldc), 0, 0);
+              continue;
+            }
             w[0] = __builtin_bit_cast(unsigned, v[0]);
             w[1] = __builtin_bit_cast(unsigned, v[1]);
             __builtin_amdgcn_raw_buffer_store_b64(w, cr, eoff(i, 0, r, p.ldc), 0, 0);
@@ -648,16 +674,20 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] += bias4[e];
-    } else if (EPI == EPI_GELU2) {
+    } else if (TWO_OUT) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[e] += bias4[e];
-        w2[e] = gelu_erf(v[e]);
+        if constexpr (EPI == EPI_GELU2D) gelu_erf_both(v[e], w2[e], v[e]);
+        else w2[e] = gelu_erf(v[e]);
       }
     } else if (EPI == EPI_RELU) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
-    } else if (EPI == EPI_DGELU || EPI == EPI_DRELU) {
+    } else if (EPI == EPI_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e] + bias4[e]);
+    } else if (ACT_GRAD || EPI == EPI_DRELU) {
       const float* ap = p.aux + (long long)m * p.ldaux + n;
       float a4[4] = {0.f, 0.f, 0.f, 0.f};
       if (evec) {
@@ -669,18 +699,18 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
           if (n + e < p.N) a4[e] = ap[e];
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = EPI == EPI_DGELU ? v[e] * gelu_erf_grad(a4[e]) : (a4[e] > 0.f ? v[e] : 0.f);
+      for (int e = 0; e < 4; ++e) v[e] = EPI == EPI_DGELU ? v[e] * gelu_erf_grad(a4[e]) : (EPI == EPI_DMUL ? v[e] * a4[e] : (a4[e] > 0.f ? v[e] : 0.f));
     }
     if (evec) {
       *reinterpret_cast<float4*>(cptr) = make_float4(v[0], v[1], v[2], v[3]);
-      if (EPI == EPI_GELU2) *reinterpret_cast<float4*>(p.C2 + (long long)m * p.ldc2 + n) = make_float4(w2[0], w2[1], w2[2], w2[3]);
+      if (TWO_OUT) *reinterpret_cast<float4*>(p.C2 + (long long)m * p.ldc2 + n) = make_float4(w2[0], w2[1], w2[2], w2[3]);
       if (LN_OK && p.ln_y) ln_piece(m, v);
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         if (n + e < p.N) {
           cptr[e] = v[e];
-          if (EPI == EPI_GELU2) p.C2[(long long)m * p.ldc2 + n + e] = w2[e];
+          if (TWO_OUT) p.C2[(long long)m * p.ldc2 + n + e] = w2[e];
         }
     }
   };
@@ -695,7 +725,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   // then each chunk is LDS reads -> arithmetic -> stores back to back, no wait in between.
   constexpr int NP = CROWS / RPP;                       // row pieces per thread and chunk
   static_assert(CROWS % RPP == 0, "epilogue row pieces");
-  constexpr bool HAS_SIDE = EPI == EPI_STORE || EPI == EPI_DGELU || EPI == EPI_DRELU;
+  constexpr bool HAS_SIDE = EPI == EPI_STORE || ACT_GRAD || EPI == EPI_DRELU;
   constexpr bool SIDE_ALL = NCHUNK == 1 && NP <= 4;     // one chunk whose side inputs fit in 16 registers: fetch them before the C image barrier
                                                         // (two-chunk tiles take the direct epilogue on the hot path; prefetching both chunks here spilled)
   const bool fast = evec && !slab;
@@ -783,19 +813,23 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
           if (use_side) { v[0] += sd[it].x; v[1] += sd[it].y; v[2] += sd[it].z; v[3] += sd[it].w; }   // same order as `finish`: residual, then bias
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bias4[e];
-        } else if (EPI == EPI_GELU2) {
+        } else if (TWO_OUT) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             v[e] += bias4[e];
-            w2[e] = gelu_erf(v[e]);
+            if constexpr (EPI == EPI_GELU2D) gelu_erf_both(v[e], w2[e], v[e]);
+            else w2[e] = gelu_erf(v[e]);
           }
         } else if (EPI == EPI_RELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e] + bias4[e], 0.f);
-        } else if (EPI == EPI_DGELU || EPI == EPI_DRELU) {
+        } else if (EPI == EPI_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e] + bias4[e]);
+        } else if (ACT_GRAD || EPI == EPI_DRELU) {
           const float a4[4] = {sd[it].x, sd[it].y, sd[it].z, sd[it].w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = EPI == EPI_DGELU ? v[e] * a4[e] : (a4[e] > 0.f ? v[e] : 0.f);
+          for (int e = 0; e < 4; ++e) v[e] = ACT_GRAD ? v[e] * a4[e] : (a4[e] > 0.f ? v[e] : 0.f);
         }
         if (m < p.M && nvalid) {
           long long crow = m;
@@ -806,7 +840,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
             ncol = cc;
           }
           *reinterpret_cast<float4*>(Cz + crow * p.ldc + ncol) = make_float4(v[0], v[1], v[2], v[3]);   // (non-temporal stores measured the same: +-1 %)
-          if (EPI == EPI_GELU2) *reinterpret_cast<float4*>(p.C2 + crow * p.ldc2 + ncol) = make_float4(w2[0], w2[1], w2[2], w2[3]);
+          if (TWO_OUT) *reinterpret_cast<float4*>(p.C2 + crow * p.ldc2 + ncol) = make_float4(w2[0], w2[1], w2[2], w2[3]);
           if (LN_OK && p.ln_y) ln_piece(m, v);
         }
       }
@@ -1438,9 +1472,12 @@ int gemm_f32(int layout, int epi, const GemmParams& p, int nsplit, hipStream_t s
   if (layout == L && epi == E) return pick_tile<L, E>(q, nsplit, vec4, th, stream);
   CASE(GEMM_NT, EPI_STORE)
   CASE(GEMM_NT, EPI_GELU2)
+  CASE(GEMM_NT, EPI_GELU2D)
+  CASE(GEMM_NT, EPI_GELU)
   CASE(GEMM_NT, EPI_RELU)
   CASE(GEMM_NN, EPI_STORE)
   CASE(GEMM_NN, EPI_DGELU)
+  CASE(GEMM_NN, EPI_DMUL)
   CASE(GEMM_NN, EPI_DRELU)
   CASE(GEMM_TN, EPI_SPLITK)
 #undef CASE

@@ -46,7 +46,7 @@ int tanh_gaussian_backward(const float*, const float*, const float*, const float
 bool block_path_supports(int B, int N, int D, int H, int dh, int M);
 long long block_path_slab_floats(int B, int N, int D, int H, int M);
 long long block_path_counters(int B, int N);
-int block_path_layer(const float* x, float* ln1, float* xmid, float* ln2, float* xout, const float* const* lp, const float* const* next_ln,
+int block_path_layer(const float* x, const float* ln1, float* xout, float* ln1_out, const float* const* lp, const float* const* next_ln,
                      int token0_only, float* slabs, int* counters, int B, int N, int D, int H, int dh, int M, hipStream_t st);
 // (frame.hip: diagnostic build only)
 bool frame_path_supports(int B, int N, int D, int H, int dh, int M);

@@ -33,6 +33,7 @@ DGVIT_KNOB(int, g_ln_fusion, 1)                 // dim 64: LayerNorms inside the
 DGVIT_KNOB(int, g_conv_gather, 1)               // conv2 / conv3 forward as implicit GEMMs
 DGVIT_KNOB(int, g_block_path, 1)                // small no-grad batches: two launches per block with in-launch combines (block.hip)
 DGVIT_KNOB(int, g_block_path_max_rows, 4160)    // ... up to this many token rows (64 frames of 65 tokens)
+DGVIT_KNOB(long long*, g_block_stamps, nullptr) // diagnostic: phase stamps of the two block kernels (32 int64)
 DGVIT_KNOB(int, g_small_path, 0)                // per-frame two-launch inference path (frame.hip; measured slower)
 DGVIT_KNOB(int, g_small_path_max_rows, 4160)
 DGVIT_KNOB(int, g_gemm_bf16_tile_hint, 0)       // bf16 GEMM tile (0 = automatic)

@@ -57,10 +57,15 @@ void dgvit_set_gemm_stamps(long long* stamps, int workgroups);
  * (DRL.py:170-185).  Correct (parity-tested) but measured slower than the split-K GEMM schedule on MI355X: each workgroup
  * walks five dependent phases of L2 round trips, see DESIGN.md 3.7. */
 void dgvit_set_small_batch_path(int on, int max_rows);
-/* A/B knob: no-grad forwards of at most max_rows token rows (default 4160 = 64 frames of 65 tokens; the workspace query sizes for
- * 4160, so a larger bound only takes effect below it) run every transformer block as TWO launches with the sums over heads / hidden
- * chunks taken inside them (block.hip; default ON in the product).  0: the seven-launch GEMM schedule for every size. */
+/* A/B knob: no-grad forwards of a few frames (at most max_rows token rows, default 4160, AND few enough workgroups to sit one per CU:
+ * dgvit_api.hip, block_path_eligible) run every transformer block as TWO launches with the sums over heads / hidden chunks taken inside
+ * them (block.hip; on = 1, the product's behaviour).  on = 0: the seven-launch GEMM schedule for every size; on = 2: the fused blocks for
+ * every shape they support, whether or not they win there (tests).  Set it before the workspace
+ * query of the call it should affect (the query sizes the combine scratch). */
 void dgvit_set_block_path(int on, int max_rows);
+/* diagnostic (tools/block_stamps.py): non-NULL = thread 0 of workgroup 0 of the two small-batch block kernels writes the 100 MHz wall clock
+ * at its phase boundaries into this device buffer of 32 int64 (attention kernel at [0..7], MLP kernel at [16..22]); NULL (default) = off. */
+void dgvit_set_block_stamps(long long* stamps);
 /* test/bench knob: force the bf16 GEMM workgroup tile (0 = automatic; 256256, 256128, 128128; 256254 = probe: per-tile kernel with
  * 4 waves of 128 x 128, profiles/r02_e_bf16_gemm_4wave_128x128_probe.txt) */
 void dgvit_set_gemm_bf16_tile(int tile);

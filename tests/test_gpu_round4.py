@@ -180,9 +180,9 @@ from helpers import knobs  # noqa: E402
 
 
 def _block_path(on):
-    """ON is the product's default for no-grad forwards of at most 4160 token rows; OFF (the seven-launch GEMM schedule) exists in the
-    diagnostic library only"""
-    return knobs(block_path=(1 if on else 0, 4160))
+    """mode 1 (the product): the fused blocks where they win (few frames); 0: the seven-launch GEMM schedule for every size; 2: the fused
+    blocks for every shape they support.  0 and 2 exist in the diagnostic library only."""
+    return knobs(block_path=(2 if on else 0, 4160))
 
 
 @pytest.mark.parametrize("name,cls", [("policy_native_shipped", "policy"), ("policy_native_small", "policy"), ("policy_c2", "policy"),
@@ -250,14 +250,18 @@ def test_block_path_equals_gemm_schedule(amd, image, patch, dim, depth, heads, d
     np.testing.assert_allclose(outs[("eval", True)].numpy(), ref.detach().numpy(), rtol=0, atol=OUT_TOL)
     assert (outs[("train", True)] - outs[("eval", True)]).abs().max().item() > 1e-3      # dropout was live in train mode
     m.eval()
-    with torch.no_grad():
+    with _block_path(True), torch.no_grad():
         again = m(img.cuda(), goal.cuda()).cpu()
-    assert torch.equal(again, outs[("eval", True)]), "the in-launch combines must sum in a fixed order"
-    # the dense last block (A/B flag) through the fused kernels too
-    m.set_schedule(dense_last_block=True)
-    with torch.no_grad():
+        assert torch.equal(again, outs[("eval", True)]), "the in-launch combines must sum in a fixed order"
+        # the dense last block (A/B flag) through the fused kernels too
+        m.set_schedule(dense_last_block=True)
         dense = m(img.cuda(), goal.cuda()).cpu()
     np.testing.assert_allclose(dense.numpy(), outs[("eval", True)].numpy(), rtol=0, atol=2e-5)
+    # ... and the product library's own choice (fused for a few frames, the GEMM schedule otherwise) gives the same features
+    m.set_schedule(dense_last_block=False)
+    with torch.no_grad():
+        prod = m(img.cuda(), goal.cuda()).cpu()
+    np.testing.assert_allclose(prod.numpy(), outs[("eval", True)].numpy(), rtol=0, atol=2e-5)
 
 
 def test_block_path_runs_two_launches_per_block(amd):
