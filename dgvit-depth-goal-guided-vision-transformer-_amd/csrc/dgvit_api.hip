@@ -17,7 +17,7 @@ int g_gemm_tile_hint = 0, g_gemm_split = 1, g_gemm_lds_pad = 0, g_gemm_persist =
 long long* g_gemm_stamps = nullptr;
 int g_gemm_stamp_capacity = 0;
 long long g_gemm_persist_launches = 0;
-int g_group_reduce = 1, g_ln_fusion = 1, g_conv_gather = 1, g_small_path = 0, g_small_path_max_rows = 4160, g_block_path = 1, g_block_path_max_rows = 4160;
+int g_group_reduce = 1, g_ln_fusion = 1, g_conv_gather = 1, g_small_path = 0, g_small_path_max_rows = 4160, g_block_path = 1, g_block_path_max_rows = 4160, g_gelu_grad_store = 1;
 int g_gemm_bf16_tile_hint = 0, g_gemm_bf16_m16 = 1, g_gemm_bf16_group_m = 8, g_attn_bwd64 = 1, g_gemm_bf16_l2_budget_kb = 2048;
 long long* g_gemm_bf16_stamps = nullptr;
 long long* g_block_stamps = nullptr;
@@ -321,6 +321,7 @@ extern "C" void dgvit_set_block_path(int on, int max_rows) {
   g_block_path_max_rows = max_rows > 0 ? max_rows : 4160;
 }
 extern "C" void dgvit_set_block_stamps(long long* stamps) { g_block_stamps = stamps; }
+extern "C" void dgvit_set_gelu_grad_store(int on) { g_gelu_grad_store = on ? 1 : 0; }
 extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = tile; }
 extern "C" void dgvit_set_gemm_bf16_mfma16(int on) { g_gemm_bf16_m16 = on ? 1 : 0; }
 extern "C" void dgvit_set_attention_bwd_single_pass(int on) { g_attn_bwd64 = on ? 1 : 0; }
@@ -524,7 +525,7 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
       p.bias = lp[L_FC1B];
       if (save) { p.C2 = lb + w.a1; p.ldc2 = d.M; }
       sk.attach(p);
-      TRY(gemm_f32(GEMM_NT, save ? EPI_GELU2D : EPI_GELU, p, 1, st));
+      TRY(gemm_f32(GEMM_NT, save ? (g_gelu_grad_store ? EPI_GELU2D : EPI_GELU2) : EPI_GELU, p, 1, st));
     }
     {
       GemmParams p = gp(lb + w.a1, d.M, lp[L_FC2W], d.M, xo, rs * d.D, tok, d.D, d.M);
@@ -661,7 +662,7 @@ extern "C" int dgvit_got_backward_ev(const dgvit_config* cfg, const float* const
       GemmParams p = gp(dx, rs * d.D, lp[L_FC2W], d.M, dh1, d.M, tok, d.M, d.D);
       p.aux = lb + w.h1; p.ldaux = d.M;             // (the h1 slot holds gelu'(pre-activation), written by the forward)
       sk.attach(p);
-      TRY(gemm_f32(GEMM_NN, EPI_DMUL, p, 1, st));   // dh1 = (dx W2) * gelu'(h1)   [previous layer's wgrads joined below]
+      TRY(gemm_f32(GEMM_NN, g_gelu_grad_store ? EPI_DMUL : EPI_DGELU, p, 1, st));   // dh1 = (dx W2) * gelu'(h1)   [previous layer's wgrads joined below]
     }
     TRY(fork());
     TRY(wgrad(dh1, d.M, lb + w.ln2, rs * d.D, lg[L_FC1W], lg[L_FC1B], d.M, d.D, tok, slabs + s.sl_fc1, s.n_fc1, sw, gq));

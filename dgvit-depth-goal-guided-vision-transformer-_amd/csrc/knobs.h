@@ -31,6 +31,7 @@ DGVIT_KNOB(int, g_gemm_stamp_capacity, 0)
 DGVIT_KNOB(int, g_group_reduce, 1)              // one grouped slab / partial reduction per layer
 DGVIT_KNOB(int, g_ln_fusion, 1)                 // dim 64: LayerNorms inside the producing GEMM's epilogue
 DGVIT_KNOB(int, g_conv_gather, 1)               // conv2 / conv3 forward as implicit GEMMs
+DGVIT_KNOB(int, g_gelu_grad_store, 1)          // training forward stores gelu'(pre-activation) for the backward (0: the pre-activation, erf in the backward epilogue)
 DGVIT_KNOB(int, g_block_path, 1)                // small no-grad batches: two launches per block with in-launch combines (block.hip)
 DGVIT_KNOB(int, g_block_path_max_rows, 4160)    // ... up to this many token rows (64 frames of 65 tokens)
 DGVIT_KNOB(long long*, g_block_stamps, nullptr) // diagnostic: phase stamps of the two block kernels (32 int64)

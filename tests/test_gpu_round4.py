@@ -284,3 +284,32 @@ def test_block_path_runs_two_launches_per_block(amd):
     lib.dgvit_profile_stop(ms, work, cnt)
     assert cnt[0] == 1, f"{cnt[0]} GEMM launches in a single-frame encoder forward (expected the patch embedding only)"
     assert cnt[1] == 0 and cnt[2] == 0
+
+
+# ------------------------------------------------------------------------------------------------ stored gelu' factor
+def test_stored_gelu_derivative_is_bit_identical_to_the_backward_epilogue_form(amd):
+    """The training forward's fc1 epilogue stores gelu'(t) where round 3 stored t, and fc2's data gradient multiplies by it instead of
+    evaluating erf / exp per element: the same operations on the same values, so every gradient must come out bit for bit the same
+    (headline shape, train mode, same dropout seed)."""
+    cfg = O.GoTConfig(image=(84, 84), patch=(12, 12), dim=256, depth=2, heads=8)
+    params = O.make_params(O.got_param_spec(cfg, prefix=""), 21)
+    m = _build_got(amd, cfg)
+    m.load_state_dict(params, strict=True)
+    m = m.cuda().train()
+    B = 6
+    img, _, _, _ = O.make_inputs(cfg, B, 21)
+    goal = torch.randn(B, cfg.dim, generator=torch.Generator().manual_seed(4)).cuda()
+    wout = torch.randn(B, cfg.dim, generator=torch.Generator().manual_seed(5)).cuda()
+    got = {}
+    for on in (1, 0):
+        with knobs(gelu_grad_store=on):
+            torch.manual_seed(9)
+            for q in m.parameters():
+                q.grad = None
+            gg = goal.clone().requires_grad_(True)
+            feat = m(img.cuda(), gg)
+            (feat * wout).sum().backward()
+            got[on] = (feat.detach().clone(), gg.grad.clone(), {k: q.grad.clone() for k, q in m.named_parameters() if q.grad is not None})
+    assert torch.equal(got[1][0], got[0][0]) and torch.equal(got[1][1], got[0][1])
+    for k in got[1][2]:
+        assert torch.equal(got[1][2][k], got[0][2][k]), k
