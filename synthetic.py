@@ -6,6 +6,7 @@ uint8-origin + noise + blur, /255: env_lab.py:295-299,432-433), goal distance U[
 """
 import glob
 import hashlib
+import json
 import os
 
 import numpy as np

@@ -1,6 +1,6 @@
 # config 5 (bf16) forward at B = 440: kernel stats, MFMA utilisation, L2 hit rate and HBM traffic per launch (separate --pmc passes)
-mkdir -p gpurun_out/r3c && export TMPDIR=/tmp
-O=gpurun_out/r3c
+mkdir -p gpurun_out/r4c5 && export TMPDIR=/tmp
+O=gpurun_out/r4c5
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 tools/c5_step.py fwd 440 7 > $O/c5.log 2>&1 && \
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_BF16 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pm -- python3 tools/c5_step.py fwd 440 2 > /dev/null 2> $O/pm.err && \
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pl -- python3 tools/c5_step.py fwd 440 2 > /dev/null 2> $O/pl.err && \
