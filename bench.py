@@ -62,35 +62,47 @@ def parse():
 
 
 def cpu_baseline(batch):
-    """The CPU oracle (same math as the reference's PyTorch-CPU path, pinned to it by tests/golden) on a
-    bounded sample: `batch` frames fwd+bwd, best of 3, all host cores."""
+    """The CPU oracle (same math as the reference's PyTorch-CPU path, pinned to it by tests/golden) on a bounded sample: `batch` frames
+    fwd+bwd, best of 3.  BASELINE.md section 4 asks for the box's host cores: on a many-core host torch's intra-op pool is not fastest
+    with one thread per core (256 threads on the 256-core box of round 4: 2.5 frames/s against 230 with 16), so a short probe picks the
+    fastest of {16, 32, 64, every core this process may run on} threads and the sample runs with that; both figures are reported."""
     from oracle import dgvit_oracle as O
     cfg = O.GoTConfig(image=IMAGE, patch=PATCH, dim=DIM, depth=DEPTH, heads=HEADS)
-    # BASELINE.md section 4: all host cores of the box (the ones this process may run on), count stated in the result
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, cores)
-    torch.set_num_threads(cores)
     params = O.make_params(O.policy_param_spec(cfg), 3407)
     for v in params.values():
         v.requires_grad_(True)
-    img, pstate, _, _ = O.make_inputs(cfg, batch, 3407)
-    tm, tl = torch.randn(batch, 2), torch.randn(batch, 2)
-    mask = (torch.rand(batch, cfg.tokens, cfg.dim) < 0.9).float()
-    best = float("inf")
-    for i in range(4):
-        t0 = time.perf_counter()
-        mean, log_std = O.policy_forward(params, img, pstate, cfg, drop_mask=mask)
-        loss = ((mean - tm) ** 2).mean() + ((log_std - tl) ** 2).mean()
-        grads = torch.autograd.grad(loss, [v for v in params.values()], allow_unused=True)
-        dt = time.perf_counter() - t0
-        if i > 0:
-            best = min(best, dt)
-    return {"value": round(batch / best, 2), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+
+    def run(nframes, passes):
+        img, pstate, _, _ = O.make_inputs(cfg, nframes, 3407)
+        tm, tl = torch.randn(nframes, 2), torch.randn(nframes, 2)
+        mask = (torch.rand(nframes, cfg.tokens, cfg.dim) < 0.9).float()
+        best = float("inf")
+        for i in range(passes + 1):
+            t0 = time.perf_counter()
+            mean, log_std = O.policy_forward(params, img, pstate, cfg, drop_mask=mask)
+            loss = ((mean - tm) ** 2).mean() + ((log_std - tl) ** 2).mean()
+            torch.autograd.grad(loss, [v for v in params.values()], allow_unused=True)
+            dt = time.perf_counter() - t0
+            if i > 0:
+                best = min(best, dt)
+        return nframes / best
+
+    probe = {}
+    for n in sorted({min(cores, 16), min(cores, 32), min(cores, 64), cores}):
+        torch.set_num_threads(n)
+        probe[n] = run(16, 1)
+    threads = max(probe, key=probe.get)
+    torch.set_num_threads(threads)
+    fps = run(batch, 3)
+    return {"value": round(fps, 2), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"oracle/dgvit_oracle.py policy fwd+bwd on {batch} of the 512 frames, train-mode mask, best of 3 after one warm-up pass, "
-                      f"{torch.get_num_threads()} torch threads = every core this process may run on ({os.cpu_count()} in the machine)"}
+                      f"{threads} torch threads = the fastest of a 16-frame probe over {{threads: frames/s}} "
+                      f"{ {k: round(v, 1) for k, v in probe.items()} } on a host with {cores} usable cores ({os.cpu_count()} in the machine)"}
 
 
 def sac_step(dgvit_amd, synthetic, B, dev, steps=5):

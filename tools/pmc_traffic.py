@@ -51,7 +51,10 @@ def main():
         print(f"{fam:18s} launches={nf:5d}  read {rd/1e6:9.2f} MB  write {wr/1e6:9.2f} MB  total {(rd+wr)/1e6:9.2f} MB per launch")
     if len(sys.argv) > 3:
         json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py --steps 3 --warmup 1; "
-                             "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read correction)", "kernels": out},
+                             "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 read correction)",
+                   # bench.py quotes these bytes only while the GEMM kernel sources they were measured on are unchanged (digest of
+                   # csrc/gemm*.hip + headers); tools/stamp_profile.py adds the commit when the file is copied into profiles/
+                   "kernel_sources_sha256": kernel_source_digest(), "kernels": out},
                   open(sys.argv[3], "w"), indent=1)
 
 
