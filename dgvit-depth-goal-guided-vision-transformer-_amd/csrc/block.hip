@@ -194,6 +194,14 @@ struct AttnBlockArgs {
   int B, N, D, H, dh, I, NQ;          // NQ: query tiles per frame that are computed (all of them, or 1: the tile of token 0)
   const float* rows;                  // (B * N, D): LayerNorm1 rows (lnw == null), or the residual stream itself (lnw != null: block 0,
   const float* lnw; const float* lnb; //             whose LayerNorm1 is applied here)
+  // block 0 can also ASSEMBLE the token rows it normalises (four launches fewer per forward): row 0 of a frame = goal + pos[0]
+  // (GoalFormer.py:160-162; rows 1 .. P come from the patch-embedding GEMM, positional embedding included), train-mode emb-dropout on all
+  // of them (:163; the Philox mask of dropout_kernel, same seed -> same mask), the assembled rows stored to `xres` by the head-0
+  // workgroups (the residual the MLP kernel reads), and the arrival counters of the MLP kernels zeroed by workgroup 0
+  const float* goal; const float* pos0;           // (B, D), (D); goal == null: the rows arrive assembled
+  float* xres;                                    // (B * N, D)
+  float keep; unsigned long long seed; const unsigned long long* seed_dev;
+  int* zero_counters; int n_counters;
   const float* wqkv; const float* wout;
   float scale;
   float* part;                        // (B, NQ, H, 32, D): every head's share of to_out for the 32 rows of a query tile
@@ -238,6 +246,15 @@ __global__ void __launch_bounds__(256) attn_block_kernel(const AttnBlockArgs a) 
       be = *reinterpret_cast<const float4*>(a.lnb + c4);
     }
     const float* src = a.rows + (long long)b * a.N * D;
+    if (a.zero_counters && blockIdx.x == 0)
+      for (int i = tid; i < a.n_counters; i += 256) a.zero_counters[i] = 0;       // (first used by the NEXT launch)
+    unsigned long long seed = a.seed;
+    if (a.goal && a.keep < 1.f && a.seed_dev) seed = *a.seed_dev;                 // graph-capturable form: the seed lives in device memory
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.goal) {
+      const float4 gv = *reinterpret_cast<const float4*>(a.goal + (long long)b * D + c4), pv = *reinterpret_cast<const float4*>(a.pos0 + c4);
+      g0 = make_float4(gv.x + pv.x, gv.y + pv.y, gv.z + pv.z, gv.w + pv.w);
+    }
     // eight row pieces per thread in flight (one dependent round trip per eight, not per piece); NP * D4 is a multiple of 256, so
     // whole waves fall out of the guards together and the LayerNorm shuffles always see whole rows
     for (int f0 = tid; f0 < NP * D4; f0 += 256 * 8) {
@@ -247,13 +264,19 @@ __global__ void __launch_bounds__(256) attn_block_kernel(const AttnBlockArgs a) 
         // (unconditional loads from a clamped row, zeroed afterwards: a load under a run-time condition is a branch around it and a
         //  full wait behind it -- the eight loads would become eight dependent round trips)
         const int f = f0 + u * 256, row = f >> d4s;
-        const float4 t = *reinterpret_cast<const float4*>(src + (long long)(row < a.N ? row : 0) * D + c4);
+        const float4 t = *reinterpret_cast<const float4*>(src + (long long)(row < a.N ? row : (a.goal ? 1 : 0)) * D + c4);
         v[u] = row < a.N ? t : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int f = f0 + u * 256, row = f >> d4s;
         if (f < NP * D4) {
+          if (a.goal) {
+            if (row == 0) v[u] = g0;
+            if (a.keep < 1.f && row < a.N) v[u] = dropout4(v[u], (((long long)b * a.N + row) * D + c4) >> 2, seed, a.keep);
+            // the assembled rows of this query tile go back to memory once per frame (head 0): the MLP kernel's residual
+            if (hd == 0 && row < a.N && (row >> 5) == qt) *reinterpret_cast<float4*>(a.xres + ((long long)b * a.N + row) * D + c4) = v[u];
+          }
           if (a.lnw) {
             const float4 y = ln_piece4(v[u], g, be, D4, invD);
             if (row < a.N) v[u] = y;
@@ -388,6 +411,7 @@ struct MlpBlockArgs {
   float* slabs; int* counters;        // [row tile][chunk][32][D] partial rows; one arrival counter per row tile (zero on entry, left zero)
   float* out;                         // (T, D) the block's output rows
   const float* lnw; const float* lnb; float* ln_out;   // the NEXT block's LayerNorm1 applied to them (or null)
+  const float* rms_g; float* feat;    // last block, pool = 'cls': feat[r] = F.normalize(row r) * sqrt(D) * g (GoalFormer.py:120-122,170), r = the tile's logical rows
   int sc1_reads;                      // the last arriver reads the other workgroups' partials with sc1 loads instead of acquiring
   long long* stamps;                  // diagnostic build: phase stamps (null in the product)
 };
@@ -574,6 +598,14 @@ __global__ void __launch_bounds__(256) mlp_block_kernel(const MlpBlockArgs a) {
           const float4 y = ln_piece4(v[e], g, be, C4, invD);
           if (live) *reinterpret_cast<float4*>(a.ln_out + grow + cc) = y;
         }
+        if (a.rms_g) {       // the final RMSNorm of the pooled token (rmsnorm_fwd_kernel's arithmetic: x / max(|x|, 1e-12) * sqrt(D) * g)
+          const float nrm = fmaxf(sqrtf(group_sum((v[e].x * v[e].x + v[e].y * v[e].y) + (v[e].z * v[e].z + v[e].w * v[e].w), C4)), 1e-12f);
+          const float sc = sqrtf((float)D);
+          const float4 gg = *reinterpret_cast<const float4*>(a.rms_g + cc);
+          if (live)
+            *reinterpret_cast<float4*>(a.feat + (long long)(rt * 32 + rr) * D + cc) =
+                make_float4(v[e].x / nrm * sc * gg.x, v[e].y / nrm * sc * gg.y, v[e].z / nrm * sc * gg.z, v[e].w / nrm * sc * gg.w);
+        }
       }
     }
   }
@@ -630,9 +662,14 @@ long long block_path_counters(int B, int N) { return ((long long)B * N + 31) / 3
 // call), or null for the first block, whose LayerNorm1 then runs inside the attention kernel; xout (T, D): the block's output;
 // lp: the block's eleven parameters in table order; next_ln (2 pointers or null): the NEXT block's LayerNorm1 weight / bias, applied
 // to xout into ln1_out.  token0_only: the block's output is read at token 0 of every frame only (the last block, pool = 'cls').
-// slabs / counters: block_path_slab_floats / block_path_counters (counters zero on entry, left zero).
+// slabs / counters: block_path_slab_floats / block_path_counters.  first (block 0 only, may be null): the attention kernel assembles
+// the token rows itself -- x holds the patch rows (+ positional embedding) from the patch-embedding GEMM, row 0 of every frame is
+// goal + pos0, emb-dropout (keep < 1) is applied to all of them, the result is stored to first->xres (which becomes the block's
+// residual stream) and the counters are zeroed by the kernel; without it the counters must be zero on entry.  They are left zero.
+// rms_g / feat (last block, token0_only): the final RMSNorm of the pooled rows runs in the MLP kernel's combine step.
 int block_path_layer(const float* x, const float* ln1, float* xout, float* ln1_out, const float* const* lp, const float* const* next_ln,
-                     int token0_only, float* slabs, int* counters, int B, int N, int D, int H, int dh, int M, hipStream_t st) {
+                     int token0_only, float* slabs, int* counters, const BlockFirst* first, const float* rms_g, float* feat, int B, int N, int D,
+                     int H, int dh, int M, hipStream_t st) {
   DGVIT_CHECK_ARG(block_path_supports(B, N, D, H, dh, M), "block path: unsupported shape");
   enum { L_LN1W = 0, L_LN1B, L_QKV, L_OUTW, L_OUTB, L_LN2W, L_LN2B, L_FC1W, L_FC1B, L_FC2W, L_FC2B };
   const int NKT = (N + 31) / 32;
@@ -640,6 +677,12 @@ int block_path_layer(const float* x, const float* ln1, float* xout, float* ln1_o
   aa.B = B; aa.N = N; aa.D = D; aa.H = H; aa.dh = dh; aa.I = H * dh; aa.NQ = token0_only ? 1 : NKT;
   aa.rows = ln1 ? ln1 : x;
   aa.lnw = ln1 ? nullptr : lp[L_LN1W]; aa.lnb = ln1 ? nullptr : lp[L_LN1B];
+  if (first) {
+    DGVIT_CHECK_ARG(!ln1 && first->goal && first->pos0 && first->xres && first->keep > 0.f && first->keep <= 1.f, "block path: bad first-block arguments");
+    aa.goal = first->goal; aa.pos0 = first->pos0; aa.xres = first->xres; aa.keep = first->keep; aa.seed = first->seed; aa.seed_dev = first->seed_dev;
+    aa.zero_counters = counters; aa.n_counters = (int)block_path_counters(B, N);
+    x = first->xres;       // the MLP kernel's residual: the assembled rows
+  }
   aa.wqkv = lp[L_QKV]; aa.wout = lp[L_OUTW];
   aa.scale = 1.0f / sqrtf((float)dh);
   aa.part = slabs;
@@ -663,6 +706,7 @@ int block_path_layer(const float* x, const float* ln1, float* xout, float* ln1_o
   ma.stamps = g_block_stamps;
 #endif
   ma.out = xout; ma.lnw = next_ln ? next_ln[0] : nullptr; ma.lnb = next_ln ? next_ln[1] : nullptr; ma.ln_out = ln1_out;
+  if (rms_g && feat && token0_only) { ma.rms_g = rms_g; ma.feat = feat; }
   static DeviceOnce once;
   if (const unsigned long long bit = once.pending()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)

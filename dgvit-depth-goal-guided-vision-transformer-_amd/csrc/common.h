@@ -159,6 +159,33 @@ __device__ __forceinline__ void gelu_erf_both(float x, float& gelu, float& grad)
   grad = gelu_erf_grad(x);
 }
 
+// ---- train-mode nn.Dropout (GoalFormer.py:144,163): Bernoulli(keep) mask / keep from Philox4x32-10 keyed by the seed, counter = the
+// float4 index of the element group in the (T, D) tensor.  One definition for the stand-alone kernel (embed.hip) and the kernels that
+// apply the mask while they stage rows (block.hip): the same seed gives the same mask wherever it is applied.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+    const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+    key.x += W0;
+    key.y += W1;
+  }
+  return ctr;
+}
+
+__device__ __forceinline__ float4 dropout4(float4 v, long long i4, unsigned long long seed, float keep) {
+  const uint4 r = philox4x32_10(make_uint4((uint32_t)i4, (uint32_t)(i4 >> 32), 0u, 0u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+  const float inv = 1.0f / keep;
+  const float sc = 2.3283064365386963e-10f;  // 2^-32
+  v.x = (r.x * sc < keep) ? v.x * inv : 0.f;
+  v.y = (r.y * sc < keep) ? v.y * inv : 0.f;
+  v.z = (r.z * sc < keep) ? v.z * inv : 0.f;
+  v.w = (r.w * sc < keep) ? v.w * inv : 0.f;
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

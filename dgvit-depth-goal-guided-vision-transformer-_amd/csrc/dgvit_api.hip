@@ -417,9 +417,9 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     sk.counters = reinterpret_cast<int*>(ws + w.sk_counters); sk.ncounters = (int)w.sk_ncounters;
     sk.slabs = ws + w.sk_slabs; sk.slab_cap = w.sk_slab_floats;
   }
-  // arrival counters of the split GEMMs and of the small-batch blocks (adjacent): every user leaves them zero again
-  if (w.sk_slab_floats > 0 || w.bp_ncounters > 0)
-    HIP_TRY(hipMemsetAsync(ws + w.sk_counters, 0, sizeof(int) * (w.bp_counters - w.sk_counters + w.bp_ncounters), st));
+  // Small no-grad batches (SAC.choose_action on one frame, the target passes of learn() on a few frames): two launches per block, the
+  // sums over heads / hidden chunks taken inside the launches (block.hip), the LayerNorms in their combine steps
+  const bool use_blocks = !save && g_block_path && !g_small_path && w.bp_ncounters > 0;
   // patch embedding (GoalFormer.py:137-139,157) + goal token, positional embedding, dropout (:160-163)
   float* patches = ws + w.patches;
   float* x = ws + w.x0;
@@ -429,6 +429,12 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
   bool gather = !save && cfg->patch_w % 4 == 0 && cfg->image_w % 4 == 0 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)params[P_PW] & 15) == 0 &&
                 (long long)d.pd * inv < (1ll << 31) && (long long)d.B * cfg->image_h * cfg->image_w < (1ll << 29);
   for (int k = 0; gather && k < d.pd; ++k) gather = (int)(((unsigned)k * (unsigned)inv) >> 16) == k / cfg->patch_w;   // exact k / pw
+  // ... with the loader gather no GEMM of this call splits, so nothing needs the counters before the first block's attention kernel,
+  // which then zeroes them itself AND assembles the token rows (goal row, emb-dropout): four launches fewer in a single-frame forward
+  const bool fused_first = use_blocks && gather;
+  // arrival counters of the split GEMMs and of the small-batch blocks (adjacent): every user leaves them zero again
+  if (!fused_first && (w.sk_slab_floats > 0 || w.bp_ncounters > 0))
+    HIP_TRY(hipMemsetAsync(ws + w.sk_counters, 0, sizeof(int) * (w.bp_counters - w.sk_counters + w.bp_ncounters), st));
   if (!gather) TRY(patchify(img, patches, d.B, cfg->image_h, cfg->image_w, cfg->patch_h, cfg->patch_w, st));
   {
     GemmParams p = gp(patches, d.pd, params[P_PW], d.pd, x, d.D, d.B * d.P, d.D, d.pd);
@@ -443,8 +449,10 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     sk.attach(p);
     TRY(gemm_f32(GEMM_NT, EPI_STORE, p, 1, st));
   }
-  TRY(goal_row(goal, params[P_POS], x, d.B, d.N, d.D, st));
-  if (keep < 1.f) TRY(dropout_inplace(x, d.T * d.D, seed, seed_dev, keep, st));
+  if (!fused_first) {
+    TRY(goal_row(goal, params[P_POS], x, d.B, d.N, d.D, st));
+    if (keep < 1.f) TRY(dropout_inplace(x, d.T * d.D, seed, seed_dev, keep, st));
+  }
 
   // inference on a handful of frames (SAC.choose_action, the no-grad passes of learn() at batch 32): two launches per block
 #ifdef DGVIT_DIAG   // (measured slower than the schedule below, DESIGN 3.7: not in the product library)
@@ -452,12 +460,13 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
     return frame_path_forward(x, params, d.L, ws + w.layer0, feat, d.B, d.N, d.D, d.H, d.dh, d.M, st);
 #endif
 
-  // Small no-grad batches (SAC.choose_action on one frame, the target passes of learn() at batch 32): two launches per block, the
-  // sums over heads / hidden chunks taken inside the launches (block.hip), the LayerNorms in their combine steps.
-  const bool use_blocks = !save && g_block_path && w.bp_ncounters > 0;
+  bool feat_done = false;
   if (use_blocks) {
-    int* counters = reinterpret_cast<int*>(ws + w.bp_counters);       // (zeroed with the split-K counters above)
+    int* counters = reinterpret_cast<int*>(ws + w.bp_counters);       // (zeroed above, or by the first attention kernel)
     float* lb = ws + w.layer0;
+    BlockFirst first = {};
+    first.goal = goal; first.pos0 = params[P_POS]; first.xres = lb + w.xmid;   // (xmid: free in this path) the assembled, dropped-out token rows
+    first.keep = keep; first.seed = seed; first.seed_dev = seed_dev;
     for (int i = 0; i < d.L; ++i) {
       const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;
       float* xo = !(i & 1) ? lb + w.xout : ws + w.layer0 + w.layer_floats;
@@ -467,12 +476,16 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
         next_ln[0] = params[P_L0 + DGVIT_PARAMS_PER_LAYER * (i + 1) + L_LN1W];
         next_ln[1] = params[P_L0 + DGVIT_PARAMS_PER_LAYER * (i + 1) + L_LN1B];
       }
-      // (block 0 normalises its input inside the attention kernel; later blocks read the rows the previous MLP kernel normalised)
+      // (block 0 normalises its input inside the attention kernel; later blocks read the rows the previous MLP kernel normalised;
+      //  the pruned last block's MLP kernel also applies the final RMSNorm to the pooled rows: GoalFormer.py:167-170)
       TRY(block_path_layer(x, i == 0 ? nullptr : lb + w.ln1, xo, lb + w.ln1, lp, i + 1 < d.L ? next_ln : nullptr, last ? 1 : 0, ws + w.bp_slabs,
-                           counters, d.B, d.N, d.D, d.H, d.dh, d.M, st));
+                           counters, i == 0 && fused_first ? &first : nullptr, last ? params[P_RMS] : nullptr, last ? feat : nullptr, d.B, d.N,
+                           d.D, d.H, d.dh, d.M, st));
+      feat_done = last;
       x = xo;
     }
   }
+  if (feat_done) return DGVIT_OK;
   const bool ln_fused = g_ln_fusion && d.D == 64 && g_gemm_tile_hint == 0;   // (the automatic tile for N = 64 is 64 wide)
   for (int i = 0; i < d.L && !use_blocks; ++i) {
     const float* const* lp = params + P_L0 + DGVIT_PARAMS_PER_LAYER * i;

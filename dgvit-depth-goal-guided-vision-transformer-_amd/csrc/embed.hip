@@ -32,33 +32,12 @@ __global__ void __launch_bounds__(256) goal_row_kernel(const float* __restrict__
   x0[b * N * D + d] = goal[idx] + pos[d];
 }
 
-__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
-    const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
-    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
-    key.x += W0;
-    key.y += W1;
-  }
-  return ctr;
-}
-
 __global__ void __launch_bounds__(256) dropout_kernel(float* __restrict__ x, long long n4, unsigned long long seed,
                                                       const unsigned long long* __restrict__ seed_dev, float keep) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n4) return;
   if (seed_dev) seed = *seed_dev;   // graph-capturable form: the seed lives in device memory
-  const uint4 r = philox4x32_10(make_uint4((uint32_t)i, (uint32_t)(i >> 32), 0u, 0u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
-  const float inv = 1.0f / keep;
-  const float sc = 2.3283064365386963e-10f;  // 2^-32
-  float4 v = reinterpret_cast<float4*>(x)[i];
-  v.x = (r.x * sc < keep) ? v.x * inv : 0.f;
-  v.y = (r.y * sc < keep) ? v.y * inv : 0.f;
-  v.z = (r.z * sc < keep) ? v.z * inv : 0.f;
-  v.w = (r.w * sc < keep) ? v.w * inv : 0.f;
-  reinterpret_cast<float4*>(x)[i] = v;
+  reinterpret_cast<float4*>(x)[i] = dropout4(reinterpret_cast<float4*>(x)[i], i, seed, keep);
 }
 
 __global__ void __launch_bounds__(256) relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out,

@@ -46,8 +46,13 @@ int tanh_gaussian_backward(const float*, const float*, const float*, const float
 bool block_path_supports(int B, int N, int D, int H, int dh, int M);
 long long block_path_slab_floats(int B, int N, int D, int H, int M);
 long long block_path_counters(int B, int N);
+struct BlockFirst {     // block 0 assembling its own token rows (block.hip)
+  const float* goal; const float* pos0; float* xres;
+  float keep; unsigned long long seed; const unsigned long long* seed_dev;
+};
 int block_path_layer(const float* x, const float* ln1, float* xout, float* ln1_out, const float* const* lp, const float* const* next_ln,
-                     int token0_only, float* slabs, int* counters, int B, int N, int D, int H, int dh, int M, hipStream_t st);
+                     int token0_only, float* slabs, int* counters, const BlockFirst* first, const float* rms_g, float* feat, int B, int N, int D,
+                     int H, int dh, int M, hipStream_t st);
 // (frame.hip: diagnostic build only)
 bool frame_path_supports(int B, int N, int D, int H, int dh, int M);
 long long frame_path_scratch_floats(int B, int N, int D, int H, int M);

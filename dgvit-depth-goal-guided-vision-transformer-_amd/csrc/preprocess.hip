@@ -53,18 +53,7 @@ __global__ void __launch_bounds__(256) normalize_trunc_kernel(const float* __res
   if (i < n) dst[(long long)blockIdx.y * n + i] = truncf(__fadd_rn(__fmul_rn(src[(long long)blockIdx.y * n + i], a), b));
 }
 
-__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
-  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
-#pragma unroll
-  for (int i = 0; i < 10; ++i) {
-    const uint32_t hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
-    const uint32_t hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
-    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
-    key.x += W0;
-    key.y += W1;
-  }
-  return ctr;
-}
+// (philox4x32_10: common.h)
 
 // dst = clip(src + noise, 0, 255); noise == null: level * N(0, 1) from Philox4x32-10 (counter = float4 index) + Box-Muller
 __global__ void __launch_bounds__(256) noise_clip_kernel(const float* __restrict__ src, const float* __restrict__ noise,
