@@ -125,7 +125,9 @@ DIAG_SIGNATURES = {
     "dgvit_set_small_batch_path": (None, [_I, _I]),
     "dgvit_set_block_path": (None, [_I, _I]),
     "dgvit_set_block_stamps": (None, [_P]),
+    "dgvit_set_block_stamp_layer": (None, [_I]),
     "dgvit_set_gelu_grad_store": (None, [_I]),
+    "dgvit_set_block_fuse": (None, [_I]),
     "dgvit_set_gemm_bf16_tile": (None, [_I]),
     "dgvit_set_gemm_bf16_group_m": (None, [_I]),
     "dgvit_set_gemm_bf16_l2_budget_kb": (None, [_I]),

@@ -687,7 +687,7 @@ int block_path_layer(const float* x, const float* ln1, float* xout, float* ln1_o
   aa.scale = 1.0f / sqrtf((float)dh);
   aa.part = slabs;
 #ifdef DGVIT_DIAG
-  aa.stamps = g_block_stamps;
+  aa.stamps = g_block_stamp_now ? g_block_stamps : nullptr;
 #endif
   int rc;
   switch (NKT) {
@@ -703,7 +703,7 @@ int block_path_layer(const float* x, const float* ln1, float* xout, float* ln1_o
   ma.w1 = lp[L_FC1W]; ma.b1 = lp[L_FC1B]; ma.w2 = lp[L_FC2W]; ma.b2 = lp[L_FC2B];
   ma.slabs = slabs + (long long)B * NKT * H * 32 * D; ma.counters = counters;
 #ifdef DGVIT_DIAG
-  ma.stamps = g_block_stamps;
+  ma.stamps = g_block_stamp_now ? g_block_stamps : nullptr;
 #endif
   ma.out = xout; ma.lnw = next_ln ? next_ln[0] : nullptr; ma.lnb = next_ln ? next_ln[1] : nullptr; ma.ln_out = ln1_out;
   if (rms_g && feat && token0_only) { ma.rms_g = rms_g; ma.feat = feat; }

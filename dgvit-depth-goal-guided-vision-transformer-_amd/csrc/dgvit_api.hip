@@ -17,10 +17,11 @@ int g_gemm_tile_hint = 0, g_gemm_split = 1, g_gemm_lds_pad = 0, g_gemm_persist =
 long long* g_gemm_stamps = nullptr;
 int g_gemm_stamp_capacity = 0;
 long long g_gemm_persist_launches = 0;
-int g_group_reduce = 1, g_ln_fusion = 1, g_conv_gather = 1, g_small_path = 0, g_small_path_max_rows = 4160, g_block_path = 1, g_block_path_max_rows = 4160, g_gelu_grad_store = 1;
+int g_group_reduce = 1, g_ln_fusion = 1, g_conv_gather = 1, g_small_path = 0, g_small_path_max_rows = 4160, g_block_path = 1, g_block_path_max_rows = 4160, g_gelu_grad_store = 1, g_block_fuse = 2;
 int g_gemm_bf16_tile_hint = 0, g_gemm_bf16_m16 = 1, g_gemm_bf16_group_m = 8, g_attn_bwd64 = 1, g_gemm_bf16_l2_budget_kb = 2048;
 long long* g_gemm_bf16_stamps = nullptr;
 long long* g_block_stamps = nullptr;
+int g_block_stamp_layer = -1, g_block_stamp_now = 1;
 #endif
 static inline bool dense_last_block(const dgvit_config* c) { return (c->flags & DGVIT_FLAG_DENSE_LAST_BLOCK) != 0; }
 static inline bool wgrad_overlap(const dgvit_config* c) { return (c->flags & DGVIT_FLAG_WGRAD_OVERLAP) != 0; }
@@ -321,7 +322,9 @@ extern "C" void dgvit_set_block_path(int on, int max_rows) {
   g_block_path_max_rows = max_rows > 0 ? max_rows : 4160;
 }
 extern "C" void dgvit_set_block_stamps(long long* stamps) { g_block_stamps = stamps; }
+extern "C" void dgvit_set_block_stamp_layer(int layer) { g_block_stamp_layer = layer; }
 extern "C" void dgvit_set_gelu_grad_store(int on) { g_gelu_grad_store = on ? 1 : 0; }
+extern "C" void dgvit_set_block_fuse(int bits) { g_block_fuse = bits & 3; }
 extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = tile; }
 extern "C" void dgvit_set_gemm_bf16_mfma16(int on) { g_gemm_bf16_m16 = on ? 1 : 0; }
 extern "C" void dgvit_set_attention_bwd_single_pass(int on) { g_attn_bwd64 = on ? 1 : 0; }
@@ -430,8 +433,11 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
                 (long long)d.pd * inv < (1ll << 31) && (long long)d.B * cfg->image_h * cfg->image_w < (1ll << 29);
   for (int k = 0; gather && k < d.pd; ++k) gather = (int)(((unsigned)k * (unsigned)inv) >> 16) == k / cfg->patch_w;   // exact k / pw
   // ... with the loader gather no GEMM of this call splits, so nothing needs the counters before the first block's attention kernel,
-  // which then zeroes them itself AND assembles the token rows (goal row, emb-dropout): four launches fewer in a single-frame forward
-  const bool fused_first = use_blocks && gather;
+  // which can then zero them itself AND assemble the token rows (goal row, emb-dropout): three launches fewer.  Built, parity-tested
+  // and NOT the default (g_block_fuse bit 0, diagnostic build): in one process, graphed sample() of the shipped actor, it measures
+  // +14 us for one frame, -3 us for two, +4 us for eight (profiles/r04_c_block_fuse_ab.txt) -- the three launches it removes were not
+  // on the critical path the way the in-kernel work that replaces them is.  The RMSNorm fusion (bit 1) is worth 2 us everywhere and stays.
+  const bool fused_first = use_blocks && gather && (g_block_fuse & 1);
   // arrival counters of the split GEMMs and of the small-batch blocks (adjacent): every user leaves them zero again
   if (!fused_first && (w.sk_slab_floats > 0 || w.bp_ncounters > 0))
     HIP_TRY(hipMemsetAsync(ws + w.sk_counters, 0, sizeof(int) * (w.bp_counters - w.sk_counters + w.bp_ncounters), st));
@@ -476,12 +482,13 @@ extern "C" int dgvit_got_forward(const dgvit_config* cfg, const float* const* pa
         next_ln[0] = params[P_L0 + DGVIT_PARAMS_PER_LAYER * (i + 1) + L_LN1W];
         next_ln[1] = params[P_L0 + DGVIT_PARAMS_PER_LAYER * (i + 1) + L_LN1B];
       }
+      DGVIT_DIAG_ONLY(g_block_stamp_now = g_block_stamp_layer < 0 || g_block_stamp_layer == i;)
       // (block 0 normalises its input inside the attention kernel; later blocks read the rows the previous MLP kernel normalised;
       //  the pruned last block's MLP kernel also applies the final RMSNorm to the pooled rows: GoalFormer.py:167-170)
       TRY(block_path_layer(x, i == 0 ? nullptr : lb + w.ln1, xo, lb + w.ln1, lp, i + 1 < d.L ? next_ln : nullptr, last ? 1 : 0, ws + w.bp_slabs,
-                           counters, i == 0 && fused_first ? &first : nullptr, last ? params[P_RMS] : nullptr, last ? feat : nullptr, d.B, d.N,
+                           counters, i == 0 && fused_first ? &first : nullptr, last && (g_block_fuse & 2) ? params[P_RMS] : nullptr, last ? feat : nullptr, d.B, d.N,
                            d.D, d.H, d.dh, d.M, st));
-      feat_done = last;
+      feat_done = last && (g_block_fuse & 2);
       x = xo;
     }
   }

@@ -33,8 +33,11 @@ DGVIT_KNOB(int, g_ln_fusion, 1)                 // dim 64: LayerNorms inside the
 DGVIT_KNOB(int, g_conv_gather, 1)               // conv2 / conv3 forward as implicit GEMMs
 DGVIT_KNOB(int, g_gelu_grad_store, 1)          // training forward stores gelu'(pre-activation) for the backward (0: the pre-activation, erf in the backward epilogue)
 DGVIT_KNOB(int, g_block_path, 1)                // small no-grad batches: two launches per block with in-launch combines (block.hip)
+DGVIT_KNOB(int, g_block_fuse, 2)                // ... bit 1 (on): the last MLP kernel applies the final RMSNorm; bit 0 (off: measured +14 us for one frame, -3 us for two): block 0 assembles its token rows
 DGVIT_KNOB(int, g_block_path_max_rows, 4160)    // ... up to this many token rows (64 frames of 65 tokens)
 DGVIT_KNOB(long long*, g_block_stamps, nullptr) // diagnostic: phase stamps of the two block kernels (32 int64)
+DGVIT_KNOB(int, g_block_stamp_layer, -1)        // ... of this transformer block only (-1: every block writes, the last one wins)
+DGVIT_KNOB(int, g_block_stamp_now, 1)           // (set by the schedule: is the block being launched the stamped one)
 DGVIT_KNOB(int, g_small_path, 0)                // per-frame two-launch inference path (frame.hip; measured slower)
 DGVIT_KNOB(int, g_small_path_max_rows, 4160)
 DGVIT_KNOB(int, g_gemm_bf16_tile_hint, 0)       // bf16 GEMM tile (0 = automatic)

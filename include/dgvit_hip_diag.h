@@ -66,10 +66,15 @@ void dgvit_set_block_path(int on, int max_rows);
 /* diagnostic (tools/block_stamps.py): non-NULL = thread 0 of workgroup 0 of the two small-batch block kernels writes the 100 MHz wall clock
  * at its phase boundaries into this device buffer of 32 int64 (attention kernel at [0..7], MLP kernel at [16..22]); NULL (default) = off. */
 void dgvit_set_block_stamps(long long* stamps);
+/* ... of transformer block `layer` only (default -1: every block writes its stamps, the last block's survive) */
+void dgvit_set_block_stamp_layer(int layer);
 /* A/B knob: 1 (default, the product) the training forward's fc1 epilogue stores gelu'(pre-activation) in the slot the backward reads and the
  * data gradient of fc2 multiplies by it; 0: the round-3 form (pre-activation stored, erf and exp evaluated in the backward epilogue).
  * Same values bit for bit; a forward and its backward must run under the same setting. */
 void dgvit_set_gelu_grad_store(int on);
+/* A/B knob of the small-batch blocks: bit 0 (default OFF: measured slower for one frame) block 0's attention kernel assembles its token rows
+ * (goal row, emb-dropout, counter zeroing: three launches fewer), bit 1 (default on) the last MLP kernel applies the final RMSNorm. */
+void dgvit_set_block_fuse(int bits);
 /* test/bench knob: force the bf16 GEMM workgroup tile (0 = automatic; 256256, 256128, 128128; 256254 = probe: per-tile kernel with
  * 4 waves of 128 x 128, profiles/r02_e_bf16_gemm_4wave_128x128_probe.txt) */
 void dgvit_set_gemm_bf16_tile(int tile);

@@ -20,7 +20,7 @@ _KNOBS = {
     "gemm_tile": ("dgvit_set_gemm_tile", (0,)), "gemm_split": ("dgvit_set_gemm_split", (1,)), "ln_fusion": ("dgvit_set_ln_fusion", (1,)),
     "conv_gather": ("dgvit_set_conv_gather", (1,)), "grouped_reduce": ("dgvit_set_grouped_reduce", (1,)),
     "gemm_diagnostics": ("dgvit_set_gemm_diagnostics", (0,)), "gemm_persistent": ("dgvit_set_gemm_persistent", (0, 0)),
-    "small_batch_path": ("dgvit_set_small_batch_path", (0, 0)), "block_path": ("dgvit_set_block_path", (1, 4160)), "gelu_grad_store": ("dgvit_set_gelu_grad_store", (1,)), "gemm_bf16_tile": ("dgvit_set_gemm_bf16_tile", (0,)),
+    "small_batch_path": ("dgvit_set_small_batch_path", (0, 0)), "block_path": ("dgvit_set_block_path", (1, 4160)), "gelu_grad_store": ("dgvit_set_gelu_grad_store", (1,)), "block_fuse": ("dgvit_set_block_fuse", (2,)), "gemm_bf16_tile": ("dgvit_set_gemm_bf16_tile", (0,)),
     "gemm_bf16_mfma16": ("dgvit_set_gemm_bf16_mfma16", (1,)), "gemm_bf16_group_m": ("dgvit_set_gemm_bf16_group_m", (8,)),
     "gemm_bf16_l2_budget_kb": ("dgvit_set_gemm_bf16_l2_budget_kb", (2048,)),
     "attention_bwd_single_pass": ("dgvit_set_attention_bwd_single_pass", (1,)), "gemm_lds_pad": ("dgvit_set_gemm_lds_pad", (0,)),

@@ -257,6 +257,15 @@ def test_block_path_equals_gemm_schedule(amd, image, patch, dim, depth, heads, d
         m.set_schedule(dense_last_block=True)
         dense = m(img.cuda(), goal.cuda()).cpu()
     np.testing.assert_allclose(dense.numpy(), outs[("eval", True)].numpy(), rtol=0, atol=2e-5)
+    # block 0 assembling its own token rows (goal row, emb-dropout with the same Philox mask, counters zeroed in the kernel): opt-in, same results
+    for mode in ("eval", "train"):
+        m.train(mode == "train")
+        with knobs(block_path=(2, 4160), block_fuse=3):
+            torch.manual_seed(5)
+            with torch.no_grad():
+                fused_first = m(img.cuda(), goal.cuda()).cpu()
+        np.testing.assert_allclose(fused_first.numpy(), outs[(mode, True)].numpy(), rtol=0, atol=2e-5, err_msg=mode)
+    m.eval()
     # ... and the product library's own choice (fused for a few frames, the GEMM schedule otherwise) gives the same features
     m.set_schedule(dense_last_block=False)
     with torch.no_grad():

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase timeline of the two small-batch block kernels (block.hip) from in-kernel wall-clock stamps (100 MHz: 10 ns steps) of workgroup 0,
-diagnostic library: python tools/block_stamps.py [batch] [dim]"""
+diagnostic library: python tools/block_stamps.py [batch] [dim] [layer (-1: the last block)] [fuse bits (3)]"""
 import os
 import sys
 
@@ -13,6 +13,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 lib = dgvit_amd.diagnostic_library().__enter__()
 lib.dgvit_set_block_path(2, 4160)
+layer = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+lib.dgvit_set_block_stamp_layer(layer)
+lib.dgvit_set_block_fuse(int(sys.argv[4]) if len(sys.argv) > 4 else 3)
 torch.manual_seed(0)
 if D == 64:
     m, image = dgvit_amd.GoTPolicy(2, 2, 4, 4, 64), (128, 160)
@@ -39,7 +42,7 @@ with torch.no_grad():
                 acc_m[i] += (v[16 + i] - v[16]) * 10.0
             comb = comb + (v[24] - v[23]) * 10.0
 lib.dgvit_set_block_stamps(None)
-print(f"attn_block_kernel, workgroup 0, B = {B}, D = {D} (ns since its start, mean of {n}; the last block: token-0 query tile only)")
+print(f"attn_block_kernel, workgroup 0, B = {B}, D = {D}, block {layer if layer >= 0 else 'last (token-0 query tile only)'}, fuse bits {sys.argv[4] if len(sys.argv) > 4 else 3} (ns since its start, mean of {n})")
 for nm, t in zip(names_a, acc_a):
     print(f"  {t / n:9.0f}  {nm}")
 print("mlp_block_kernel, workgroup 0 (its 'combined' stamp is only meaningful when workgroup 0 arrived last)")
