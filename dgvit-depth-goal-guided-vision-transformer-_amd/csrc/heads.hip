@@ -169,20 +169,44 @@ __global__ void __launch_bounds__(256) mlp_head_bwd_kernel(const HeadArgs a) {
   float* o_b2 = a.direct ? a.db2[t] : part + po.b2;
 
   stage_x(a, xs, row0, tid);
-#pragma unroll 4
-  for (int f = tid; f < HR * a.n1; f += 256) {
-    const int r = f / a.n1, c = f % a.n1;
-    h1s[r * S1 + c] = row0 + r < a.B ? a.h1[((long long)t * a.B + row0 + r) * a.n1 + c] : 0.f;
-  }
-#pragma unroll 4
-  for (int f = tid; f < HR * a.n2; f += 256) {
-    const int r = f / a.n2, c = f % a.n2;
-    h2s[r * S2 + c] = row0 + r < a.B ? a.h2[((long long)t * a.B + row0 + r) * a.n2 + c] : 0.f;
+  // h1 / h2 rows (n1, n2 multiples of 32: whole float4 pieces) -> LDS: every piece of a thread is requested before the first is used,
+  // from a clamped row (rows past the batch are zeroed afterwards).  The per-element form this replaces compiled to one load and one
+  // `s_waitcnt vmcnt(0)` per element -- 32 dependent L2 round trips in front of the first MFMA of a kernel that is one workgroup's
+  // latency chain (round 4: 69 -> 4x us at batch 512).
+  auto stage_rows = [&](float* dst, int SD, const float* __restrict__ src, int n) {
+    const int n4 = n >> 2, total = HR * n4;
+    for (int f0 = tid; f0 < total; f0 += 256 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = f0 + u * 256 < total ? f0 + u * 256 : 0, r = f / n4, c = (f - r * n4) * 4;
+        const int row = row0 + r < a.B ? row0 + r : a.B - 1;
+        v[u] = *reinterpret_cast<const float4*>(src + ((long long)t * a.B + row) * n + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int f = f0 + u * 256;
+        if (f < total) {
+          const int r = f / n4, c = (f - r * n4) * 4;
+          *reinterpret_cast<float4*>(dst + r * SD + c) = row0 + r < a.B ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+  };
+  stage_rows(h1s, S1, a.h1, a.n1);
+  stage_rows(h2s, S2, a.h2, a.n2);
+  // third-layer weights W3_j (n3 x n2 each, <= 2 x 4 x 128 floats) -> LDS: the dh2 loop below reads every element 32 times
+  float* w3s = dys + a.heads3 * HR * a.n3;
+  for (int f = tid; f < a.heads3 * a.n3 * a.n2; f += 256) {
+    const int j = f / (a.n3 * a.n2);
+    w3s[f] = (j ? a.w3[t][1] : a.w3[t][0])[f - j * a.n3 * a.n2];
   }
   for (int f = tid; f < a.heads3 * HR * a.n3; f += 256) {
     const int o = f % a.n3, row = (f / a.n3) % HR, j = f / (a.n3 * HR);
     const float* dyj = j ? a.dyp[t][1] : a.dyp[t][0];   // (a per-lane index into a kernel-argument array would go through scratch memory)
-    dys[f] = (dyj && row0 + row < a.B) ? dyj[(long long)(row0 + row) * a.n3 + o] : 0.f;
+    const int rc = row0 + row < a.B ? row0 + row : a.B - 1;
+    const float v = dyj ? dyj[(long long)rc * a.n3 + o] : 0.f;
+    dys[f] = row0 + row < a.B ? v : 0.f;
   }
   __syncthreads();
   // dh2 = relu'(h2) o sum_j dy_j W3_j
@@ -190,7 +214,7 @@ __global__ void __launch_bounds__(256) mlp_head_bwd_kernel(const HeadArgs a) {
     const int r = f / a.n2, c = f % a.n2;
     float s = 0.f;
     for (int j = 0; j < a.heads3; ++j)
-      for (int o = 0; o < a.n3; ++o) s = fmaf(dys[(j * HR + r) * a.n3 + o], a.w3[t][j][(long long)o * a.n2 + c], s);
+      for (int o = 0; o < a.n3; ++o) s = fmaf(dys[(j * HR + r) * a.n3 + o], w3s[(j * a.n3 + o) * a.n2 + c], s);
     g2s[r * S2 + c] = h2s[r * S2 + c] > 0.f ? s : 0.f;
   }
   // dW3_j[o][c] = sum_rows dy_j[row][o] h2[row][c];  db3_j[o] = sum_rows dy_j[row][o]
@@ -301,7 +325,7 @@ __global__ void __launch_bounds__(256) head_dx_add_kernel(const HeadArgs a) {
 
 size_t fwd_lds(int KP, int n1, int n2) { return sizeof(float) * HR * ((size_t)(KP + 4) + (n1 + 4) + (n2 + 4)); }
 size_t bwd_lds(int KP, int n1, int n2, int n3, int heads3) {
-  return sizeof(float) * (HR * ((size_t)(KP + 4) + 2 * (n1 + 4) + 2 * (n2 + 4)) + (size_t)heads3 * HR * n3 + 4);
+  return sizeof(float) * (HR * ((size_t)(KP + 4) + 2 * (n1 + 4) + 2 * (n2 + 4)) + (size_t)heads3 * HR * n3 + (size_t)heads3 * n3 * n2 + 4);
 }
 
 int fill_args(HeadArgs& a, const dgvit_mlp_desc* d, const float* const* in, const float* const* params) {
