@@ -293,18 +293,22 @@ __global__ void __launch_bounds__(256) mlp_head_bwd_kernel(const HeadArgs a) {
       zero16(acc);
       mm_rows_x_wcols(acc, g1s, S1, a.w1[t], a.K0, k, a.K0, a.n1, li, h);
       if (k < a.K0) {
-        int kk = k, sg = 0;
-        while (sg + 1 < a.nseg && kk >= a.kx[sg]) { kk -= a.kx[sg]; ++sg; }
-        float* d = a.dx[sg];
-        if (d) {
+        // which input piece column k belongs to: selected with ?: (a per-lane index into the kernel-argument arrays is a load from
+        // memory, and inside the store loop below it was one dependent round trip per accumulator register: 16 in a row)
+        const int k0 = a.kx[0], k1 = a.nseg > 1 ? a.kx[1] : 0;
+        const int sg = (a.nseg > 1 && k >= k0) ? ((a.nseg > 2 && k >= k0 + k1) ? 2 : 1) : 0;
+        const int kk = sg == 0 ? k : (sg == 1 ? k - k0 : k - k0 - k1);
+        float* d = sg == 0 ? a.dx[0] : (sg == 1 ? a.dx[1] : a.dx[2]);
+        const long long ldd = sg == 0 ? a.lddx[0] : (sg == 1 ? a.lddx[1] : a.lddx[2]);
+        // both towers of a twin head run in this launch: tower 0 writes dx, tower 1 its own buffer, added afterwards in a fixed order
+        const bool own = t == 1 && a.dx1;
+        float* dst = !d ? nullptr : (own ? a.dx1 + k : d + kk);       // (a piece without a gradient slot gets none from either tower)
+        const long long ldo = own ? a.K0 : ldd;
+        if (dst) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = row0 + arow(r, h);
-            if (row < a.B) {
-              // both towers of a twin head run in this launch: tower 0 writes dx, tower 1 its own buffer, added afterwards in a fixed order
-              if (t == 1 && a.dx1) a.dx1[(long long)row * a.K0 + k] = acc[r];
-              else d[(long long)row * a.lddx[sg] + kk] = acc[r];
-            }
+            if (row < a.B) dst[(long long)row * ldo] = acc[r];
           }
         }
       }
