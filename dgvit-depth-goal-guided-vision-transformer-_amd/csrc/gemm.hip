@@ -1408,6 +1408,9 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
 // tile-quantisation and prologue bound, so they take small tiles: wide outputs 64x128x16, narrow 64x64x32
 inline int auto_tile(int layout, int M, int N) {
   if (layout == GEMM_TN) return (M >= 128 && N >= 128) ? 128128032 : 64064032;
+  // (round 4 re-run of the table, profiles/r04_c_gemm_tiles.txt: the choices stand, except the data gradient of to_out -- NN, N = 512,
+  //  K = 256 -- which gains 5 % on the wide tile)
+  if (layout == GEMM_NN && N >= 512) return 64128016;
   return N >= 1024 ? 64128016 : 64064032;
 }
 
