@@ -16,6 +16,16 @@
 //    1 (B, the L2-resident weights) to 2.5 (A) periods of ~2 k cycles to land.
 //  * THE DMA ISSUE IS SPREAD over the MFMAs (one instruction per eight MFMAs): issued as a burst of 4 x 8 waves the memory pipeline's
 //    queue backs up and the issuing waves stall in front of it.
+//  * ONE WAVE OF EVERY SIMD PAIR ISSUES THE DMAs OF BOTH (round 4).  Waves w and w + 4 share a SIMD; per-wave clock stamps showed the pair
+//    out of balance: from the barrier on, waves 0-3 ran their second half in ~970 cycles and waves 4-7 in ~1540, so waves 0-3 sat ~870
+//    cycles per k-tile at the next barrier while their partners worked alone, too slowly to keep the MFMA pipe busy (2.7 k cycles per k-tile
+//    for 2.05 k of matrix work).  The matrix work cannot move between waves (the accumulators are theirs), the DMA issue can: waves 0-3
+//    issue all eight instructions per piece (their own rows and their partner's, 32 rows / four 1 KB chunks away), waves 4-7 none.
+//    Stamps after: 1040 + 1010 busy and 460 waiting (waves 0-3) against 1320 + 1060 + 145 (waves 4-7), 2.52 k cycles per k-tile; launches at
+//    batch 440: fc2 332 -> 308-316 us, QKV 264-287 -> 254-262, fc1 397-402 -> 394-396 (bit-identical results; profiles/r04_d_stream_dma_sharing.txt).
+//    The opposite assignment (waves 4-7 issue) loses; a priority window for waves 4-7 on top is worth at most another 1.5 % on fc1 only and
+//    stays a timing variant.  Since a wave's epilogue staging chunks are now overwritten by ANOTHER wave's DMAs, one more barrier per output
+//    tile separates the epilogue from the next first half (measured free).
 //  * DIRECT EPILOGUE.  The MFMA operands are swapped (weights as the A operand), so a lane's four accumulator registers of a
 //    16 x 16 block are four CONSECUTIVE output columns of one row: bias / GELU / bf16 conversion and one 8-byte (bf16) or
 //    16-byte (fp32) buffer store straight from registers.  No LDS staging, no wave barriers, no VMEM loads: the bias comes in by
@@ -23,8 +33,9 @@
 //    flight (cdna_hip_programming.md, "Pipelining across barriers") -- a whole ring of DMA latency per tile.
 //  * Persistent as before: one workgroup per CU walks tiles id, id + grid, ...; the k-tile stream runs on across tile boundaries.
 // vmcnt bookkeeping (loads, LDS-DMAs and stores retire in order on one counter): piece j is issued in the half-phase that
-// precedes... see the loop; every wait is `vmcnt(4)` (the piece issued during the current phase may stay in flight), so the
-// stores of an epilogue simply have to be older than the next barrier's wait, which they are by a whole k-tile period.
+// precedes... see the loop; every wait of an issuing wave is `vmcnt(8)` (the piece issued during the current phase may stay in flight),
+// so the stores of an epilogue simply have to be older than the next barrier's wait, which they are by a whole k-tile period; a wave
+// that issues no DMAs waits for none (its partner's counted wait followed by the barrier orders its rows).
 #include "bf16.h"
 #include "kernels.h"
 
@@ -84,6 +95,15 @@ __device__ __forceinline__ void sched_half() {
     __builtin_amdgcn_sched_group_barrier(0x8, 8, 0);
     return;
   }
+  if (VAR == 6 || VAR == 7) {          // DMA sharing: the issuing wave one DMA per row block (eight per half), its partner none
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (VAR == 6) __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+    }
+    return;
+  }
   if (VAR == 4) {          // its partner: DMAs and fragment reads first, matrix work behind them
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -110,13 +130,24 @@ __device__ __forceinline__ void sched_half() {
 
 // Timing diagnostics (diagnostic build only, dgvit_set_gemm_diagnostics; results are garbage): bit 0 (1) every piece re-fetches k-tile 0
 // of its tile (cache-hot source), bit 1 (2) no LDS-DMA at all, bit 2 (4) no fragment reads inside the loop, bit 3 (8) no epilogue,
-// bit 4 (16) no barrier, bit 5 (32) no MFMAs, bit 6 (64, with 8) the accumulators stay alive without an epilogue.
+// bit 4 (16) no barrier, bit 5 (32) no MFMAs, bit 6 (64, with 8) the accumulators stay alive without an epilogue; 32768 every wave issues
+// its own DMAs (the round-3 schedule), 65536 waves 4-7 issue them all, 131072 / 262144 priority window for waves 4-7 (exact results),
+// 524288 no barrier after the epilogue (racy).
 // (compile-time variants: a run-time test around every MFMA wrecks the very schedule being measured)
 #define SDIAG(b) ((DIAG & (b)) != 0)
+constexpr int dma_sharing(int DIAG) { return SDIAG(65536) ? 2 : (SDIAG(32768) || SDIAG(256) || SDIAG(128) || SDIAG(4096)) ? 0 : 1; }
 
 template <int EPI, int DIAG, int ROLE>     // ROLE: 0 every wave the same schedule; 1 / 2 leading / trailing wave of a SIMD pair (timing variant 256)
 __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles) {
-  constexpr int HVAR = ROLE == 1 ? 3 : ROLE == 2 ? 4 : SDIAG(4096) ? 5 : SDIAG(128) ? 1 : 0;
+  // DMA sharing (see the file header): 1 waves 0-3 issue the LDS-DMAs of their SIMD partners too (the shipped schedule), 2 waves 4-7 do
+  // (timing variant 65536), 0 every wave issues its own (round 3; timing variant 32768 and the variants that bring their own half schedule)
+  constexpr int DSH = dma_sharing(DIAG);
+  constexpr bool ISSUER = DSH != 0 && ROLE == DSH;
+  constexpr int NDMA = DSH == 0 ? 4 : ISSUER ? 8 : 0;            // piece DMAs this wave issues per half
+  // ... and the partner runs the first PK row blocks of every SECOND half (the one that starts at the barrier, where the older wave of the
+  // pair otherwise wins every issue slot) at priority 1 (timing variants 131072 / 262144 on top: PK = 2 / 4 / 6)
+  constexpr int PK = DSH != 0 && !ISSUER ? 2 * ((DIAG >> 17) & 3) : 0;
+  constexpr int HVAR = DSH ? (ISSUER ? 6 : 7) : ROLE == 1 ? 3 : ROLE == 2 ? 4 : SDIAG(4096) ? 5 : SDIAG(128) ? 1 : 0;
   constexpr bool OUT_F32 = EPI == BEPI_F32_PLAIN;
   // Output stores are non-temporal (aux bit 1): C is never read again by this launch and is larger than the L2s, so letting it allocate there
   // only evicts the A / B k-slices that the neighbouring tiles are about to re-read (measured at B = 440: QKV 313 -> 278 us, fc1 420 -> 394 us,
@@ -187,15 +218,19 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
   // Past the last tile the same instructions still issue (every lane out of range: zeros into a free slot): the vmcnt bookkeeping
   // never changes.
   unsigned ldead = lchunk * 8 < p.K ? 0u : OOB;
-  auto dma_a = [&](int i) {
+  // (`other`: the rows of the SIMD partner, wave ^ 4 -- 32 rows and four 1 KB chunks away, same swizzle since (wave & 1) is the same)
+  const int pw = wave < 4 ? 4 : -4;
+  auto dma_a = [&](int i, int other = 0) {
     if constexpr (!SDIAG(2))
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(smem + lslot * PIECE + wave * 1024 + i * 8192), 16,
-                                               ((offA + (SDIAG(1) ? 0u : (unsigned)lt * 128u)) | ldead) + i * stepA, 0, 0, SDIAG(8192) ? 2 : 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(smem + lslot * PIECE + (wave + other * pw) * 1024 + i * 8192), 16,
+                                               ((offA + (SDIAG(1) ? 0u : (unsigned)lt * 128u)) | ldead) + i * stepA + (unsigned)(other * pw * 16 * p.lda), 0, 0,
+                                               SDIAG(8192) ? 2 : 0);
   };
-  auto dma_b = [&](int i) {
+  auto dma_b = [&](int i, int other = 0) {
     if constexpr (!SDIAG(2))
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(smem + lslot * PIECE + wave * 1024 + i * 8192), 16,
-                                               ((offB + (SDIAG(1) ? 0u : (unsigned)lt * 128u)) | ldead) + i * stepB, 0, 0, SDIAG(16384) ? 2 : 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(smem + lslot * PIECE + (wave + other * pw) * 1024 + i * 8192), 16,
+                                               ((offB + (SDIAG(1) ? 0u : (unsigned)lt * 128u)) | ldead) + i * stepB + (unsigned)(other * pw * 16 * p.ldb), 0, 0,
+                                               SDIAG(16384) ? 2 : 0);
   };
   auto next_slot = [&]() { lslot = lslot + 1 == NSLOT ? 0 : lslot + 1; };
   auto next_ktile = [&]() {     // after the B piece
@@ -239,14 +274,20 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_a(i);
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (NDMA > 0) dma_a(i);
+      if constexpr (ISSUER) dma_a(i, 1);
+    }
     next_slot();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_b(i);
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (NDMA > 0) dma_b(i);
+      if constexpr (ISSUER) dma_b(i, 1);
+    }
     next_slot();
     next_ktile();
   }
-  wait_vmcnt<8>();
+  wait_vmcnt<2 * NDMA>();
   __builtin_amdgcn_s_barrier();
   {
     const unsigned char* sA = smem + a_off, *sB = smem + PIECE + b_off;
@@ -285,7 +326,9 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
 #pragma unroll
         for (int j = 0; j < 4; ++j) if constexpr (!SDIAG(32)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[j], fa0[i], acc[i][j], 0, 0, 0);
         if constexpr (!SDIAG(4)) fa1[i] = *reinterpret_cast<const bf16x8*>(sA + i * 2048);
-        if ((i & 1) == PAR) dma_a(i >> 1);
+        if constexpr (DSH != 0) {
+          if constexpr (ISSUER) dma_a(i >> 1, i & 1);
+        } else if ((i & 1) == PAR) dma_a(i >> 1);
       }
       sched_half<HVAR, PAR>();
       };
@@ -298,13 +341,16 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
     // Right after an epilogue the tile's NST stores are younger than those pieces too and may stay in flight (every one of them is
     // issued unconditionally, invalid rows / columns go out of range, so the count is exact): waiting for their acknowledgement
     // here would stall the first k-tile of every tile behind the write stream.
-    if (after_epi) {
-      wait_vmcnt<(4 + NST <= 63 ? 4 + NST : 63)>();
-      after_epi = false;
-    } else {
-      wait_vmcnt<4>();
+    if constexpr (NDMA > 0) {     // (a wave that issues no DMAs has nothing to wait for: its partner's counted wait and the barrier cover its rows)
+      if (after_epi) {
+        wait_vmcnt<(NDMA + NST <= 63 ? NDMA + NST : 63)>();
+        after_epi = false;
+      } else {
+        wait_vmcnt<NDMA>();
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PK > 0) __builtin_amdgcn_s_setprio(1);
     if constexpr (!SDIAG(16)) __builtin_amdgcn_s_barrier();        // k-tile t + 1 is complete; the slots of k-tile t are free
     STAMP_ADD(st_wait)
     __builtin_amdgcn_sched_barrier(0);
@@ -330,7 +376,12 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
 #pragma unroll
         for (int j = 0; j < 4; ++j) if constexpr (!SDIAG(32)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[j], fa1[i], acc[i][j], 0, 0, 0);
         if constexpr (!SDIAG(4)) fa0[i] = *reinterpret_cast<const bf16x8*>(nA + i * 2048);
-        if ((i & 1) == PAR) dma_b(i >> 1);
+        if constexpr (PK > 0) {
+          if (i == PK - 1) __builtin_amdgcn_s_setprio(0);
+        }
+        if constexpr (DSH != 0) {
+          if constexpr (ISSUER) dma_b(i >> 1, i & 1);
+        } else if ((i & 1) == PAR) dma_b(i >> 1);
       }
       sched_half<HVAR, PAR>();
       };
@@ -372,7 +423,7 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
       const unsigned coloff = n0 + wc * 64 + 4 * rc < p.N ? (unsigned)(wc * 64 + 4 * rc) * ES : OOB;
       fx4 bv[4];
       if (EPI != BEPI_F32_PLAIN && p.bias) {
-        wait_vmcnt<4>();      // the bias DMA (issued before this phase's four piece DMAs) has landed; same wave: no barrier needed
+        wait_vmcnt<NDMA>();   // the bias DMA (issued before this phase's four piece DMAs) has landed; same wave: no barrier needed
 #pragma unroll
         for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const fx4*>(stg + (16 * j + 4 * q) * 4);
         wait_lgkm0();
@@ -458,6 +509,8 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
         }
       }
     }
+    // DMA sharing: the partner's next DMAs go into THIS wave's staging chunks of slot s1 -- every wave must be out of its epilogue first
+    if constexpr (DSH != 0 && !SDIAG(524288)) __builtin_amdgcn_s_barrier();     // (524288: timing only, racy)
     } else if constexpr (SDIAG(64)) {   // timing: main loop with its MFMAs, nothing stored (the accumulators are kept alive, then cleared)
 #pragma unroll
       for (int i = 0; i < 8; ++i)
@@ -488,7 +541,7 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
 
 template <int EPI, int DIAG = 0>
 __global__ void __launch_bounds__(512) gemm_bf16_stream_kernel(const GemmBf16Params p, int ntiles) {
-  if constexpr (SDIAG(256)) {
+  if constexpr (SDIAG(256) || dma_sharing(DIAG) != 0) {
     if (threadIdx.x < 256) stream_body<EPI, DIAG, 1>(p, ntiles);     // waves 0-3: one per SIMD
     else stream_body<EPI, DIAG, 2>(p, ntiles);                       // waves 4-7: their partners
   } else {
@@ -574,7 +627,7 @@ int gemm_bf16_stream(int epi, const GemmBf16Params& p, hipStream_t st) {
   if (g_gemm_diag && (epi == BEPI_BF16 || epi == BEPI_GELU_BF16)) {
 #define DGVIT_SD(D)                                                                        \
   if (g_gemm_diag == D) return epi == BEPI_BF16 ? launch_stream<BEPI_BF16, D>(p, st) : launch_stream<BEPI_GELU_BF16, D>(p, st);
-    DGVIT_SD(1) DGVIT_SD(2) DGVIT_SD(4) DGVIT_SD(8) DGVIT_SD(10) DGVIT_SD(14) DGVIT_SD(18) DGVIT_SD(30) DGVIT_SD(32) DGVIT_SD(40) DGVIT_SD(41) DGVIT_SD(44) DGVIT_SD(16) DGVIT_SD(72) DGVIT_SD(73) DGVIT_SD(74) DGVIT_SD(76) DGVIT_SD(88) DGVIT_SD(128) DGVIT_SD(256) DGVIT_SD(512) DGVIT_SD(768) DGVIT_SD(1024) DGVIT_SD(1536) DGVIT_SD(1280) DGVIT_SD(2048) DGVIT_SD(2049) DGVIT_SD(3072) DGVIT_SD(4096) DGVIT_SD(4168) DGVIT_SD(8192) DGVIT_SD(16384) DGVIT_SD(24576)
+    DGVIT_SD(1) DGVIT_SD(2) DGVIT_SD(4) DGVIT_SD(8) DGVIT_SD(10) DGVIT_SD(14) DGVIT_SD(18) DGVIT_SD(30) DGVIT_SD(32) DGVIT_SD(40) DGVIT_SD(41) DGVIT_SD(44) DGVIT_SD(16) DGVIT_SD(72) DGVIT_SD(73) DGVIT_SD(74) DGVIT_SD(76) DGVIT_SD(88) DGVIT_SD(128) DGVIT_SD(256) DGVIT_SD(512) DGVIT_SD(768) DGVIT_SD(1024) DGVIT_SD(1536) DGVIT_SD(1280) DGVIT_SD(2048) DGVIT_SD(2049) DGVIT_SD(3072) DGVIT_SD(4096) DGVIT_SD(4168) DGVIT_SD(8192) DGVIT_SD(16384) DGVIT_SD(24576) DGVIT_SD(32768) DGVIT_SD(65536) DGVIT_SD(33280) DGVIT_SD(33792) DGVIT_SD(131072) DGVIT_SD(262144) DGVIT_SD(393216) DGVIT_SD(524288)
 #undef DGVIT_SD
     return dgvit_set_error(DGVIT_ERR_ARG, "gemm_bf16_stream: no timing variant %d", g_gemm_diag);
   }

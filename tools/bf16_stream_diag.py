@@ -14,11 +14,13 @@ lib = dgvit_amd.diagnostic_library().__enter__()
 T = B * 197
 g = torch.Generator(device="cuda").manual_seed(0)
 # timing variants of gemm_bf16_stream_kernel (csrc/gemm_bf16_stream.hip, SDIAG bits): 1 cache-hot source, 2 no DMA, 4 no fragment reads,
-# 8 no epilogue, 16 no barrier, 32 no MFMA, 64 accumulators kept alive without an epilogue, 128 DMA amid the MFMAs, 256 SIMD partners
+# 32768 / 65536 who issues the LDS-DMAs, 131072.. priority window of waves 4-7, 8 no epilogue, 16 no barrier, 32 no MFMA, 64 accumulators kept alive without an epilogue, 128 DMA amid the MFMAs, 256 SIMD partners
 # lead / trail, 512 per-wave stamps (tools/bf16_stream_stamps.py), 1024 waves 4-7 at priority 1, 2048 ORDINARY output stores (the
 # shipped kernel's are non-temporal)
-ARMS = [("stream (warm-up)", 256257, 0), ("stream", 256257, 0), ("A loads non-temporal", 256257, 8192), ("B loads non-temporal", 256257, 16384),
-        ("A and B loads non-temporal", 256257, 24576), ("stream again", 256257, 0), ("A nt again", 256257, 8192), ("B nt again", 256257, 16384)]
+ARMS = [("stream (warm-up)", 256257, 0), ("stream", 256257, 0), ("every wave issues its own DMAs (round 3)", 256257, 32768), ("waves 4-7 issue every DMA", 256257, 65536),
+        ("waves 4-7 at priority 1", 256257, 1024), ("priority window 2", 256257, 131072), ("priority window 4", 256257, 262144),
+        ("stream again", 256257, 0), ("round 3 again", 256257, 32768), ("window 4 again", 256257, 262144)]
+EXACT = (32768, 65536, 1024, 131072, 262144)     # variants that compute the real result: checked bit for bit against the shipped schedule
 
 
 def timeit(fn, iters=20, warm=3):
@@ -43,6 +45,11 @@ for name, (m, n, k, epi) in {"qkv": (T, 2304, 768, 0), "fc1": (T, 3072, 768, 1),
             continue
         lib.dgvit_set_gemm_bf16_tile(tile)
         lib.dgvit_set_gemm_diagnostics(diag)
+        if diag in EXACT:
+            got = F.op_gemm_bf16(epi, x, w, bias=bias)
+            lib.dgvit_set_gemm_diagnostics(0)
+            assert torch.equal(got, F.op_gemm_bf16(epi, x, w, bias=bias)), (name, arm)
+            lib.dgvit_set_gemm_diagnostics(diag)
         ms = timeit(lambda: F.op_gemm_bf16(epi, x, w, bias=bias))
         print(f"{name} ({m}, {n}, {k}) {arm:24s} {ms * 1e3:8.1f} us  {2.0 * m * n * k / ms / 1e9:8.1f} TFLOP/s-equivalent", flush=True)
     lib.dgvit_set_gemm_diagnostics(0)
