@@ -526,17 +526,36 @@ __global__ void __launch_bounds__(256, 3) attn_bwd64_kernel(const float* __restr
     float4 qf[DH / 8], dof[DH / 8];
     float delta, lq;
     {
+      // EVERY global load of the workgroup is issued before the first one is waited for -- the K / V staging pieces (NP * DH / 4 / 256
+      // float4 per thread and matrix, rows >= N read row 0 and are zeroed), then the q / dO / O row fragments and the row's lse: one
+      // memory round trip.  (stage_pair() after the delta sum cost a second one: the sum waits for the fragments, and its loop issued
+      // half of its loads for pieces past the image.)
+      constexpr int C4 = DH / 4, PER = NP * C4 / 256;
+      float4 kst[PER], vst[PER];
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int f = tid + j * 256, row = f / C4, c = (f % C4) * 4;
+        const int rr = row < N ? row : 0;
+        kst[j] = *reinterpret_cast<const float4*>(base + I + rr * ld + c);
+        vst[j] = *reinterpret_cast<const float4*>(base + 2 * I + rr * ld + c);
+      }
       float4 of[DH / 8];
       row_frags<DH>(qf, base + qc * ld, qv, h, qscale);
       row_frags<DH>(dof, dobase + (long long)qc * I, qv, h, 1.f);
       row_frags<DH>(of, obase + (long long)qc * I, qv, h, 1.f);
       lq = qv ? lse[((long long)b * H + hd) * N + qc] : 0.f;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int f = tid + j * 256, row = f / C4, c = (f % C4) * 4;
+        const float k = row < N ? 1.f : 0.f;   // (a float4 ?: would be lowered through scratch memory)
+        *reinterpret_cast<float4*>(X + row * SK + c) = make_float4(kst[j].x * k, kst[j].y * k, kst[j].z * k, kst[j].w * k);
+        *reinterpret_cast<float4*>(Y + row * SK + c) = make_float4(vst[j].x * k, vst[j].y * k, vst[j].z * k, vst[j].w * k);
+      }
       float d = 0.f;
 #pragma unroll
       for (int g = 0; g < DH / 8; ++g) d += (dof[g].x * of[g].x + dof[g].y * of[g].y) + (dof[g].z * of[g].z + dof[g].w * of[g].w);
       delta = d + __shfl_xor(d, 32, 64);
     }
-    stage_pair<DH, SK, 256>(X, base + I, ld, Y, base + 2 * I, ld, N, NP, tid);
     __syncthreads();
     f32x16 sT, dpT;
 #pragma unroll
@@ -556,11 +575,21 @@ __global__ void __launch_bounds__(256, 3) attn_bwd64_kernel(const float* __restr
     f32x16 dq[DT];
     zero_tiles<DT>(dq);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (kt * 32 + acc_row(r, 0) >= N) continue;     // both keys of the step are padding (dS = 0): wave-uniform skip
-      const float* krow = X + (kt * 32 + acc_row(r, h)) * SK + li;
+    for (int g4 = 0; g4 < 4; ++g4) {
+      // four k-steps = eight keys at a time, their K values read from LDS as one batch in front of the eight MFMAs (a read and a wait per
+      // MFMA pair left the LDS latency exposed sixteen times); a group of eight padding keys (dS = 0) is skipped, wave-uniform
+      if (kt * 32 + 8 * g4 >= N) continue;
+      float kv[4][DT];
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[dt * 32], dsT[r], dq[dt], 0, 0, 0);
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float* krow = X + (kt * 32 + acc_row(4 * g4 + r4, h)) * SK + li;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) kv[r4][dt] = krow[dt * 32];
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[r4][dt], dsT[4 * g4 + r4], dq[dt], 0, 0, 0);
     }
     __syncthreads();                 // every wave is done with the K / V images
     // ---- step 2: dQ = partial(kt = 0) + partial(kt = 1), through the (now free) X image, rows = queries
@@ -605,15 +634,20 @@ __global__ void __launch_bounds__(256, 3) attn_bwd64_kernel(const float* __restr
     zero_tiles<DT>(dv);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      if (qt * 32 + 8 * g >= N) continue;             // eight padding queries (dO = 0): wave-uniform skip
       const float4 pf = *reinterpret_cast<const float4*>(T + key * TQ + qt * 32 + 8 * g + 4 * h);
       const float pe[4] = {pf.x, pf.y, pf.z, pf.w};
+      float dov[4][DT];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (qt * 32 + 8 * g + e >= N) continue;       // both queries of the step are padding (dO = 0): wave-uniform skip
         const float* dorow = Y + (qt * 32 + 8 * g + 4 * h + e) * SK + li;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow[dt * 32], pe[e], dv[dt], 0, 0, 0);
+        for (int dt = 0; dt < DT; ++dt) dov[e][dt] = dorow[dt * 32];
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dov[e][dt], pe[e], dv[dt], 0, 0, 0);
     }
     __syncthreads();                 // P^T has been consumed
 #pragma unroll
@@ -621,15 +655,20 @@ __global__ void __launch_bounds__(256, 3) attn_bwd64_kernel(const float* __restr
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      if (qt * 32 + 8 * g >= N) continue;             // (dS = 0)
       const float4 sf = *reinterpret_cast<const float4*>(T + key * TQ + qt * 32 + 8 * g + 4 * h);
       const float se[4] = {sf.x, sf.y, sf.z, sf.w};
+      float qv4[4][DT];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        if (qt * 32 + 8 * g + e >= N) continue;       // (dS = 0)
         const float* qrow = X + (qt * 32 + 8 * g + 4 * h + e) * SK + li;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[dt * 32], se[e], dk[dt], 0, 0, 0);
+        for (int dt = 0; dt < DT; ++dt) qv4[e][dt] = qrow[dt * 32];
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qv4[e][dt], se[e], dk[dt], 0, 0, 0);
     }
     __syncthreads();                 // the dS^T image and the Q / dO images have been consumed
     // ---- step 4: dK / dV = partial(qt = 0) + partial(qt = 1), through the T / X regions, rows = keys
