@@ -721,6 +721,137 @@ int launch_bwd64(const float* qkv, const float* o, const float* dout, const floa
   return DGVIT_OK;
 }
 
+// ------------------------------------------------------------------------------------ ONE query (token 0), N <= 64: no matrix cores
+// The last block of the encoder keeps token 0 only (GoalFormer.py:167 reads x[:, 0]): its attention has one query row per (frame, head).
+// On the tile kernels above that row is 1 of 32 rows of an MFMA tile and the launch is all latency (forward 49 us, backward 124 us at the
+// C3 shape for 105 / 210 MB of K, V, dK, dV).  Here a WAVE takes one (frame, head): DH / 4 adjacent lanes hold one key's K and V rows as
+// float4 pieces (whole 128 / 256-byte row segments per load instruction, 64 * 4 / DH keys per instruction, every load of the wave issued
+// before the first is used), the dot products are DPP butterflies over those lanes, and the softmax / weighted sums are a handful of FMAs.
+// Plain fp32 FMAs: not bit-identical to the MFMA kernels' summation order, same 1e-6-level agreement as between any two of them.
+template <int W>
+__device__ __forceinline__ float lanes_sum(float v) {     // over W adjacent lanes (butterfly: every lane ends with the sum)
+#pragma unroll
+  for (int o = W >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int W>
+__device__ __forceinline__ float groups_sum(float v) {    // over the 64 / W groups of W lanes
+#pragma unroll
+  for (int o = W; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+template <int DH>
+__global__ void __launch_bounds__(256) attn_q1_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ lse,
+                                                          int N, int H, float scale, int items) {
+  constexpr int C4 = DH / 4, G = 64 / C4, NI = 64 / G;     // lanes per key, keys per step, steps (64 keys)
+  const int lane = threadIdx.x & 63, item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= items) return;                                // (wave-uniform; no barriers in this kernel)
+  const int b = item / H, hd = item - b * H, I = H * DH;
+  const long long ld = 3ll * I;
+  const int c = lane % C4, g = lane / C4;
+  const float* base = qkv + (long long)b * N * ld + hd * DH + 4 * c;
+  float4 kf[NI], vf[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int key = i * G + g, rr = key < N ? key : 0;
+    kf[i] = *reinterpret_cast<const float4*>(base + I + rr * ld);
+    vf[i] = *reinterpret_cast<const float4*>(base + 2 * I + rr * ld);
+  }
+  float4 q = *reinterpret_cast<const float4*>(base);
+  const float qscale = scale * DGVIT_LOG2E;
+  q = make_float4(q.x * qscale, q.y * qscale, q.z * qscale, q.w * qscale);
+  float sc[NI], m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const float d = lanes_sum<C4>(dot4(q, kf[i]));
+    sc[i] = i * G + g < N ? d : -INFINITY;
+    m = fmaxf(m, sc[i]);
+  }
+#pragma unroll
+  for (int o = C4; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));     // (key 0 is real: m is finite)
+  float l = 0.f;
+  float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const float pv = __builtin_amdgcn_exp2f(sc[i] - m);     // exp2(-inf) = 0 for the padding keys
+    l += pv;
+    o4.x += pv * vf[i].x; o4.y += pv * vf[i].y; o4.z += pv * vf[i].z; o4.w += pv * vf[i].w;
+  }
+  l = groups_sum<C4>(l);
+  o4 = make_float4(groups_sum<C4>(o4.x), groups_sum<C4>(o4.y), groups_sum<C4>(o4.z), groups_sum<C4>(o4.w));
+  if (g == 0) {
+    const float inv = 1.f / l;
+    *reinterpret_cast<float4*>(out + (long long)b * N * I + hd * DH + 4 * c) = make_float4(o4.x * inv, o4.y * inv, o4.z * inv, o4.w * inv);
+  }
+  if (lse && lane == 0) lse[((long long)b * H + hd) * N] = m + __builtin_amdgcn_logf(l);   // base-2 log-sum-exp
+}
+
+template <int DH>
+__global__ void __launch_bounds__(256) attn_q1_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o_fwd,
+                                                          const float* __restrict__ d_out, const float* __restrict__ lse,
+                                                          float* __restrict__ dqkv, int N, int H, float scale, int items) {
+  constexpr int C4 = DH / 4, G = 64 / C4, NI = 64 / G;
+  const int lane = threadIdx.x & 63, item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= items) return;
+  const int b = item / H, hd = item - b * H, I = H * DH;
+  const long long ld = 3ll * I;
+  const int c = lane % C4, g = lane / C4;
+  const float* base = qkv + (long long)b * N * ld + hd * DH + 4 * c;
+  float* gbase = dqkv + (long long)b * N * ld + hd * DH + 4 * c;
+  float4 kf[NI], vf[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int key = i * G + g, rr = key < N ? key : 0;
+    kf[i] = *reinterpret_cast<const float4*>(base + I + rr * ld);
+    vf[i] = *reinterpret_cast<const float4*>(base + 2 * I + rr * ld);
+  }
+  const float4 q = *reinterpret_cast<const float4*>(base);
+  const float4 dof = *reinterpret_cast<const float4*>(d_out + (long long)b * N * I + hd * DH + 4 * c);
+  const float4 of = *reinterpret_cast<const float4*>(o_fwd + (long long)b * N * I + hd * DH + 4 * c);
+  const float lq = lse[((long long)b * H + hd) * N];
+  const float qscale = scale * DGVIT_LOG2E;
+  const float4 qs = make_float4(q.x * qscale, q.y * qscale, q.z * qscale, q.w * qscale);
+  const float delta = lanes_sum<C4>(dot4(dof, of));
+  float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int key = i * G + g;
+    const float sv = lanes_sum<C4>(dot4(qs, kf[i])), dp = lanes_sum<C4>(dot4(dof, vf[i]));
+    const float pv = key < N ? __builtin_amdgcn_exp2f(sv - lq) : 0.f;
+    const float ds = pv * (dp - delta) * scale;
+    if (key < N) {
+      *reinterpret_cast<float4*>(gbase + I + key * ld) = make_float4(ds * q.x, ds * q.y, ds * q.z, ds * q.w);
+      *reinterpret_cast<float4*>(gbase + 2 * I + key * ld) = make_float4(pv * dof.x, pv * dof.y, pv * dof.z, pv * dof.w);
+    }
+    dq.x += ds * kf[i].x; dq.y += ds * kf[i].y; dq.z += ds * kf[i].z; dq.w += ds * kf[i].w;
+  }
+  dq = make_float4(groups_sum<C4>(dq.x), groups_sum<C4>(dq.y), groups_sum<C4>(dq.z), groups_sum<C4>(dq.w));
+  if (g == 0) *reinterpret_cast<float4*>(gbase) = dq;
+}
+
+template <int DH>
+int launch_q1_fwd(const float* qkv, float* out, float* lse, int B, int N, int H, float scale, hipStream_t stream) {
+  const int items = B * H;
+  const int slot = profile_begin(PROF_ATTN_FWD, 4.0 * items * (double)N * DH, stream);
+  hipLaunchKernelGGL(attn_q1_fwd_kernel<DH>, dim3((items + 3) / 4), dim3(256), 0, stream, qkv, out, lse, N, H, scale, items);
+  profile_end(slot, stream);
+  DGVIT_CHECK_LAUNCH("attention_fwd (one query)");
+  return DGVIT_OK;
+}
+
+template <int DH>
+int launch_q1_bwd(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, int B, int N, int H, float scale,
+                  hipStream_t stream) {
+  const int items = B * H;
+  const int slot = profile_begin(PROF_ATTN_BWD, 8.0 * items * (double)N * DH, stream);
+  hipLaunchKernelGGL(attn_q1_bwd_kernel<DH>, dim3((items + 3) / 4), dim3(256), 0, stream, qkv, o, dout, lse, dqkv, N, H, scale, items);
+  profile_end(slot, stream);
+  DGVIT_CHECK_LAUNCH("attention_bwd (one query)");
+  return DGVIT_OK;
+}
+
 constexpr int MAX_TOKENS = 224;
 
 template <int DH, int NW, int NKT_CT>
@@ -784,6 +915,10 @@ int attention_fwd(const float* qkv, float* out, float* lse, int B, int N, int H,
   DGVIT_CHECK_ARG(nq >= 1 && nq <= N, "attention_fwd: bad query count");
   DGVIT_CHECK_ARG(N <= MAX_TOKENS && (dh == 64 || dh == 32), "attention_fwd: unsupported dim_head=%d / tokens=%d (dim_head 64 or 32, N <= 224)", dh, N);
   const float scale = 1.0f / sqrtf((float)dh);
+  if (g_attn_q1 && nq == 1 && N <= 64) {                               // token 0 only (the last block): one wave per (frame, head)
+    if (dh == 64) return launch_q1_fwd<64>(qkv, out, lse, B, N, H, scale, stream);
+    return launch_q1_fwd<32>(qkv, out, lse, B, N, H, scale, stream);
+  }
   if (nq == N && N > 32 && N <= 64 && (long long)B * H >= 2048) {      // many short sequences: the pipelined form
     if (dh == 64) return launch_fwd_pipe<64>(qkv, out, lse, B, N, H, scale, stream);
     return launch_fwd_pipe<32>(qkv, out, lse, B, N, H, scale, stream);
@@ -802,6 +937,10 @@ int attention_bwd(const float* qkv, const float* o, const float* dout, const flo
   DGVIT_CHECK_ARG(nq >= 1 && nq <= N, "attention_bwd: bad query count");
   DGVIT_CHECK_ARG(N <= MAX_TOKENS && (dh == 64 || dh == 32), "attention_bwd: unsupported dim_head=%d / tokens=%d", dh, N);
   const float scale = 1.0f / sqrtf((float)dh);
+  if (g_attn_q1 && nq == 1 && N <= 64) {
+    if (dh == 64) return launch_q1_bwd<64>(qkv, o, dout, lse, dqkv, B, N, H, scale, stream);
+    return launch_q1_bwd<32>(qkv, o, dout, lse, dqkv, B, N, H, scale, stream);
+  }
   if (g_attn_bwd64 && nq == N && N > 32 && N <= 64) {   // the DGViT-small token counts: every tile pair computed once
     if (dh == 64) return launch_bwd64<64>(qkv, o, dout, lse, dqkv, B, N, H, scale, stream);
     return launch_bwd64<32>(qkv, o, dout, lse, dqkv, B, N, H, scale, stream);

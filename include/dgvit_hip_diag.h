@@ -86,6 +86,13 @@ void dgvit_set_gemm_bf16_l2_budget_kb(int kb);
 /* A/B knob: 1 (default) the single-pass fp32 attention backward for 32 < N <= 64 (every tile pair computed once); 0 the two-phase
  * kernel for every shape.  Same results up to summation order. */
 void dgvit_set_attention_bwd_single_pass(int on);
+/* 0: a one-query attention (the last block's token 0) runs on the MFMA tile kernels as before round 4; 1 (default): attn_q1_*_kernel */
+void dgvit_set_attention_single_query(int on);
+/* dgvit_attention_forward / _backward (dgvit_hip.h) for the first nq query tokens only, as the encoder's last block calls them with nq = 1
+ * (GoalFormer.py:167 reads x[:, 0]): rows >= nq of out / lse / dq are not written, dk and dv cover every key */
+int dgvit_attention_forward_queries(const float* qkv, float* out, float* lse, int B, int N, int H, int dh, int nq, void* stream);
+int dgvit_attention_backward_queries(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv, int B, int N, int H,
+                                     int dh, int nq, void* stream);
 /* A/B knob: which MFMA the ring GEMM issues: 1 (default) v_mfma_f32_16x16x32_bf16, 0 v_mfma_f32_32x32x16_bf16 (same cycles per
  * FLOP; the kernel runs under the chip's power limit and the 16x16 shape measured 2-3 % faster; same results up to summation order) */
 void dgvit_set_gemm_bf16_mfma16(int on);

@@ -322,3 +322,54 @@ def test_stored_gelu_derivative_is_bit_identical_to_the_backward_epilogue_form(a
     assert torch.equal(got[1][0], got[0][0]) and torch.equal(got[1][1], got[0][1])
     for k in got[1][2]:
         assert torch.equal(got[1][2][k], got[0][2][k]), k
+
+
+# ------------------------------------------------------------------------------------------------ one-query attention (the last block's token 0)
+@pytest.mark.parametrize("B,N,H,dh", [(37, 50, 8, 64), (5, 37, 4, 64), (3, 64, 2, 64), (9, 17, 4, 32), (2, 1, 1, 64), (130, 50, 8, 32), (4, 33, 1, 64)])
+def test_single_query_attention_matches_torch_and_the_tile_kernels(amd, B, N, H, dh):
+    """GoalFormer.py:167 reads x[:, 0]: the last block's attention has one query row per (frame, head).  attn_q1_fwd / attn_q1_bwd (plain
+    fp32 FMAs, a wave per (frame, head)) against torch autograd on the same row, and against the MFMA tile kernels they replace."""
+    import ctypes
+    from dgvit_amd import functional as F
+    g = torch.Generator(device="cuda").manual_seed(1000 * N + B)
+    I = H * dh
+    qkv = torch.randn(B, N, 3 * I, device="cuda", generator=g)
+    dout0 = torch.randn(B, I, device="cuda", generator=g)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+
+    def run(lib):
+        out = torch.full((B, N, I), 7.0, device="cuda")
+        lse = torch.full((B, H, N), 7.0, device="cuda")
+        dqkv = torch.full_like(qkv, 7.0)
+        dout = torch.zeros(B, N, I, device="cuda")
+        dout[:, 0] = dout0
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert lib.dgvit_attention_forward_queries(ptr(qkv), ptr(out), ptr(lse), B, N, H, dh, 1, st) == 0
+        assert lib.dgvit_attention_backward_queries(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), B, N, H, dh, 1, st) == 0
+        torch.cuda.synchronize()
+        return out, lse, dqkv
+
+    with amd.diagnostic_library() as lib:
+        out, lse, dqkv = run(lib)
+        with knobs(attention_single_query=0):
+            out_t, lse_t, dqkv_t = run(lib)
+    # rows the one-query form must not touch
+    assert torch.all(out[:, 1:] == 7.0) and torch.all(lse[:, :, 1:] == 7.0) and torch.all(dqkv[:, 1:, :I] == 7.0)
+    x = qkv.detach().clone().requires_grad_(True)
+    q, k, v = (t.view(B, N, H, dh).transpose(1, 2) for t in x.split(I, dim=-1))
+    s = (q[:, :, :1] @ k.transpose(-1, -2)) * dh ** -0.5
+    ref = (s.softmax(-1) @ v).transpose(1, 2).reshape(B, I)
+    ref.backward(dout0)
+    ref_lse = torch.logsumexp(s[:, :, 0], dim=-1) * 1.4426950408889634
+    np.testing.assert_allclose(out[:, 0].cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(lse[:, :, 0].cpu().numpy(), ref_lse.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    want = x.grad
+    got = dqkv.clone()
+    got[:, 1:, :I] = 0.0                                   # (not written: no gradient reaches the other queries)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 1e-5 * scale + 1e-7
+    # ... and the tile kernels agree to the same level (different summation order)
+    np.testing.assert_allclose(out[:, 0].cpu().numpy(), out_t[:, 0].cpu().numpy(), rtol=1e-5, atol=2e-6)
+    got_t = dqkv_t.clone()
+    got_t[:, 1:, :I] = 0.0
+    assert float((got - got_t).abs().max()) <= 1e-5 * scale + 1e-7
