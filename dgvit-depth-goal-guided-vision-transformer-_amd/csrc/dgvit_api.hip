@@ -311,7 +311,7 @@ extern "C" void dgvit_set_gemm_persistent(int mode, int workgroups) {
   g_gemm_persist = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
   g_gemm_persist_grid = workgroups > 0 ? workgroups : 0;
 }
-extern "C" void dgvit_set_gemm_diagnostics(int on) { g_gemm_diag = on & 0xFFFFF; }
+extern "C" void dgvit_set_gemm_diagnostics(int on) { g_gemm_diag = on & 0x3FFFFF; }
 extern "C" void dgvit_set_gemm_lds_pad(int bytes) { g_gemm_lds_pad = bytes > 0 ? bytes : 0; }
 extern "C" void dgvit_set_small_batch_path(int on, int max_rows) {
   g_small_path = on ? 1 : 0;

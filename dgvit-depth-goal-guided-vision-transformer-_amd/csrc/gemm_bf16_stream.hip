@@ -72,9 +72,22 @@ __device__ __forceinline__ void wait_vmcnt() {
 // the 32 DMA instructions a CU issues per half arrive at the memory pipeline evenly (~1 per 32 cycles; it takes ~1 per 24): issued
 // as a burst at the top of the half they back up its queue and the waves stall in front of it before their first MFMA.
 // (LLVM SchedGroupMask: MFMA 0x8, VMEM 0x10, DS read 0x100.)
-template <int VAR, int PAR>
+template <int VAR, int PAR, int LEAD = 0>
 __device__ __forceinline__ void sched_half() {
   __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+  if ((VAR == 6 || VAR == 7) && LEAD > 0) {   // fragment reads LEAD row blocks ahead of the matrix work: the half's last read is issued with
+                                             // 4 * LEAD MFMAs still to come instead of behind the last one (timing variants 1048576 / 2097152)
+                                             // -- measured 2-4 % SLOWER on fc1 / fc2 (profiles/r04_d_stream_dma_sharing.txt, run 4): bunched reads
+                                             // collide with the DMA writes in the LDS; the one-read-per-block spread stays
+    __builtin_amdgcn_sched_group_barrier(0x100, LEAD, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+      if (i < 8 - LEAD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (VAR == 6) __builtin_amdgcn_sched_group_barrier(0x10, 1, 0);
+    }
+    return;
+  }
   if (VAR == 3) {          // leading wave of a SIMD pair: matrix work first (fragment reads between the blocks), the four DMAs at the end
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -147,6 +160,7 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
   // ... and the partner runs the first PK row blocks of every SECOND half (the one that starts at the barrier, where the older wave of the
   // pair otherwise wins every issue slot) at priority 1 (timing variants 131072 / 262144 on top: PK = 2 / 4 / 6)
   constexpr int PK = DSH != 0 && !ISSUER ? 2 * ((DIAG >> 17) & 3) : 0;
+  constexpr int LEAD = SDIAG(1048576) ? 2 : SDIAG(2097152) ? 4 : 0;
   constexpr int HVAR = DSH ? (ISSUER ? 6 : 7) : ROLE == 1 ? 3 : ROLE == 2 ? 4 : SDIAG(4096) ? 5 : SDIAG(128) ? 1 : 0;
   constexpr bool OUT_F32 = EPI == BEPI_F32_PLAIN;
   // Output stores are non-temporal (aux bit 1): C is never read again by this launch and is larger than the L2s, so letting it allocate there
@@ -330,7 +344,7 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
           if constexpr (ISSUER) dma_a(i >> 1, i & 1);
         } else if ((i & 1) == PAR) dma_a(i >> 1);
       }
-      sched_half<HVAR, PAR>();
+      sched_half<HVAR, PAR, LEAD>();
       };
       first_half(std::integral_constant<int, 1>{});
     }
@@ -383,7 +397,7 @@ __device__ __forceinline__ void stream_body(const GemmBf16Params& p, int ntiles)
           if constexpr (ISSUER) dma_b(i >> 1, i & 1);
         } else if ((i & 1) == PAR) dma_b(i >> 1);
       }
-      sched_half<HVAR, PAR>();
+      sched_half<HVAR, PAR, LEAD>();
       };
       second_half(std::integral_constant<int, 1>{});
     }
@@ -627,7 +641,7 @@ int gemm_bf16_stream(int epi, const GemmBf16Params& p, hipStream_t st) {
   if (g_gemm_diag && (epi == BEPI_BF16 || epi == BEPI_GELU_BF16)) {
 #define DGVIT_SD(D)                                                                        \
   if (g_gemm_diag == D) return epi == BEPI_BF16 ? launch_stream<BEPI_BF16, D>(p, st) : launch_stream<BEPI_GELU_BF16, D>(p, st);
-    DGVIT_SD(1) DGVIT_SD(2) DGVIT_SD(4) DGVIT_SD(8) DGVIT_SD(10) DGVIT_SD(14) DGVIT_SD(18) DGVIT_SD(30) DGVIT_SD(32) DGVIT_SD(40) DGVIT_SD(41) DGVIT_SD(44) DGVIT_SD(16) DGVIT_SD(72) DGVIT_SD(73) DGVIT_SD(74) DGVIT_SD(76) DGVIT_SD(88) DGVIT_SD(128) DGVIT_SD(256) DGVIT_SD(512) DGVIT_SD(768) DGVIT_SD(1024) DGVIT_SD(1536) DGVIT_SD(1280) DGVIT_SD(2048) DGVIT_SD(2049) DGVIT_SD(3072) DGVIT_SD(4096) DGVIT_SD(4168) DGVIT_SD(8192) DGVIT_SD(16384) DGVIT_SD(24576) DGVIT_SD(32768) DGVIT_SD(65536) DGVIT_SD(33280) DGVIT_SD(33792) DGVIT_SD(131072) DGVIT_SD(262144) DGVIT_SD(393216) DGVIT_SD(524288)
+    DGVIT_SD(1) DGVIT_SD(2) DGVIT_SD(4) DGVIT_SD(8) DGVIT_SD(10) DGVIT_SD(14) DGVIT_SD(18) DGVIT_SD(30) DGVIT_SD(32) DGVIT_SD(40) DGVIT_SD(41) DGVIT_SD(44) DGVIT_SD(16) DGVIT_SD(72) DGVIT_SD(73) DGVIT_SD(74) DGVIT_SD(76) DGVIT_SD(88) DGVIT_SD(128) DGVIT_SD(256) DGVIT_SD(512) DGVIT_SD(768) DGVIT_SD(1024) DGVIT_SD(1536) DGVIT_SD(1280) DGVIT_SD(2048) DGVIT_SD(2049) DGVIT_SD(3072) DGVIT_SD(4096) DGVIT_SD(4168) DGVIT_SD(8192) DGVIT_SD(16384) DGVIT_SD(24576) DGVIT_SD(32768) DGVIT_SD(65536) DGVIT_SD(33280) DGVIT_SD(33792) DGVIT_SD(131072) DGVIT_SD(262144) DGVIT_SD(393216) DGVIT_SD(524288) DGVIT_SD(1048576) DGVIT_SD(2097152) DGVIT_SD(1049088) DGVIT_SD(2097664)
 #undef DGVIT_SD
     return dgvit_set_error(DGVIT_ERR_ARG, "gemm_bf16_stream: no timing variant %d", g_gemm_diag);
   }

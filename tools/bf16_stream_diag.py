@@ -17,10 +17,9 @@ g = torch.Generator(device="cuda").manual_seed(0)
 # 32768 / 65536 who issues the LDS-DMAs, 131072.. priority window of waves 4-7, 8 no epilogue, 16 no barrier, 32 no MFMA, 64 accumulators kept alive without an epilogue, 128 DMA amid the MFMAs, 256 SIMD partners
 # lead / trail, 512 per-wave stamps (tools/bf16_stream_stamps.py), 1024 waves 4-7 at priority 1, 2048 ORDINARY output stores (the
 # shipped kernel's are non-temporal)
-ARMS = [("stream (warm-up)", 256257, 0), ("stream", 256257, 0), ("every wave issues its own DMAs (round 3)", 256257, 32768), ("waves 4-7 issue every DMA", 256257, 65536),
-        ("waves 4-7 at priority 1", 256257, 1024), ("priority window 2", 256257, 131072), ("priority window 4", 256257, 262144),
-        ("stream again", 256257, 0), ("round 3 again", 256257, 32768), ("window 4 again", 256257, 262144)]
-EXACT = (32768, 65536, 1024, 131072, 262144)     # variants that compute the real result: checked bit for bit against the shipped schedule
+ARMS = [("stream (warm-up)", 256257, 0), ("stream", 256257, 0), ("fragment reads 2 blocks ahead", 256257, 1048576), ("fragment reads 4 blocks ahead", 256257, 2097152),
+        ("stream again", 256257, 0), ("2 ahead again", 256257, 1048576), ("4 ahead again", 256257, 2097152)]
+EXACT = (32768, 65536, 1024, 131072, 262144, 1048576, 2097152)     # variants that compute the real result: checked bit for bit against the shipped schedule
 
 
 def timeit(fn, iters=20, warm=3):
