@@ -19,7 +19,7 @@ from synthetic import kernel_source_digest  # noqa: E402
 
 
 def family(name):
-    for key in ("gemm_f32_kernel", "gemm_bf16_stream_kernel", "gemm_bf16_ring_kernel", "attn_fwd_bf16_stream", "attn_fwd_pipe_kernel", "attn_fwd_kernel", "attn_bwd_kernel", "attn_bwd64_kernel",
+    for key in ("gemm_f32_kernel", "gemm_bf16_stream_kernel", "gemm_bf16_ring_kernel", "attn_fwd_bf16_stream", "attn_fwd_pipe_kernel", "attn_fwd_kernel", "attn_bwd_kernel", "attn_bwd64_kernel", "attn_q1_fwd_kernel", "attn_q1_bwd_kernel",
                 "reduce_slabs", "layernorm_fwd", "layernorm_bwd"):
         if key in name:
             return key
