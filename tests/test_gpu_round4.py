@@ -373,3 +373,39 @@ def test_single_query_attention_matches_torch_and_the_tile_kernels(amd, B, N, H,
     got_t = dqkv_t.clone()
     got_t[:, 1:, :I] = 0.0
     assert float((got - got_t).abs().max()) <= 1e-5 * scale + 1e-7
+
+
+# ------------------------------------------------------------------------------------------------ stream GEMM: who issues the LDS-DMAs
+@pytest.mark.parametrize("M,N,K", [(86680 // 8, 2304, 768), (1000, 776, 200), (257, 264, 72), (5000, 3072, 768), (4099, 768, 3080)])
+@pytest.mark.parametrize("epi", [0, 1, 4, 5])
+def test_stream_gemm_dma_sharing_is_bit_identical_to_the_round3_schedule(amd, M, N, K, epi):
+    """gemm_bf16_stream.hip: waves 0-3 issue the LDS-DMAs of their SIMD partners too (round 4).  Only WHO issues a load changes: every
+    epilogue must equal the schedule in which every wave issues its own (timing variant 32768 of the diagnostic build) bit for bit,
+    including ragged M / N / K (out-of-range rows of the partner's DMAs) and the extra barrier behind the epilogue."""
+    from dgvit_amd import functional as F
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+
+    def run():
+        if epi == 5:
+            return F.op_gemm_bf16(1, x, w, bias=bias, want_c2=True)
+        return (F.op_gemm_bf16(epi, x, w, bias=None if epi == 4 else bias),)
+
+    with knobs(force_diag=True, gemm_bf16_tile=256257) as lib:
+        new = run()
+        if epi in (0, 1):
+            lib.dgvit_set_gemm_diagnostics(32768)
+            try:
+                old = run()
+            finally:
+                lib.dgvit_set_gemm_diagnostics(0)
+            for a, b in zip(new, old):
+                assert torch.equal(a, b)
+    ref = x.float() @ w.float().t() + (0 if epi == 4 else bias)
+    got = new[-1].float() if epi == 5 else new[0].float()     # (epilogue 5: c2 is the pre-activation copy)
+    if epi in (1,):
+        ref = torch.nn.functional.gelu(ref)
+    tol = 2e-2 if epi != 4 else 1e-3
+    assert float((got - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
