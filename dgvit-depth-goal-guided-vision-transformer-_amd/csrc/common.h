@@ -103,6 +103,7 @@ struct GemmSplitPlan {
 };
 // the split decision for C (M x N) = A B over K with the tile the automatic choice picks; used for sizing and at launch
 GemmSplitPlan gemm_split_plan(int layout, int M, int N, int K);
+GemmSplitPlan gemm_split_plan_gather(int M, int N, int K);   // A gathered from an image: the 64 x 64 x 32 tile
 
 // live timing hooks (profile.hip); slot < 0 = not recording
 int profile_begin(int kind, double work, hipStream_t st);

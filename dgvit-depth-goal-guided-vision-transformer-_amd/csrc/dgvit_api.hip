@@ -154,13 +154,17 @@ struct Dims {
 struct SplitNeed {
   long long slab = 0;
   long long tiles = 0;
-  void add(int layout, long long M, int N, int K) {
-    if (M <= 0) return;
-    const GemmSplitPlan pl = gemm_split_plan(layout, (int)M, N, K);
+  void take(const GemmSplitPlan& pl) {
     if (pl.nsplit > 1) {
       slab = std::max(slab, pl.slab_floats);
       tiles = std::max<long long>(tiles, pl.tiles);
     }
+  }
+  void add(int layout, long long M, int N, int K) {
+    if (M > 0) take(gemm_split_plan(layout, (int)M, N, K));
+  }
+  void add_gather(long long M, int N, int K) {     // A gathered from an image (fixed 64 x 64 x 32 tile)
+    if (M > 0) take(gemm_split_plan_gather((int)M, N, K));
   }
 };
 struct SplitBuf {
@@ -196,6 +200,7 @@ SplitNeed forward_split_need(const Dims& d) {
   SplitNeed n;
   const int T = (int)d.T;
   n.add(GEMM_NT, (long long)d.B * d.P, d.D, d.pd);
+  n.add_gather((long long)d.B * d.P, d.D, d.pd);
   n.add(GEMM_NT, T, 3 * d.I, d.D); n.add(GEMM_NT, T, 2 * d.I, d.D); n.add(GEMM_NT, d.B, d.I, d.D);
   for (int tok : {T, d.B}) {
     n.add(GEMM_NT, tok, d.D, d.I); n.add(GEMM_NT, tok, d.M, d.D); n.add(GEMM_NT, tok, d.D, d.M);
@@ -938,10 +943,20 @@ extern "C" long long dgvit_cnn_workspace_floats(int B, int H, int W) {
   if (make_conv_dims(B, H, W, d)) return -1;
   return al4(d.M[1] * 16) + al4(d.M[2] * 64) + al4(d.M[3] * 256);
 }
+// split-K scratch of the forward's implicit-GEMM convolutions (conv2 / conv3; conv1 goes through im2col and is not split)
+static SplitNeed conv_split_need(const ConvDims& d) {
+  SplitNeed n;
+  for (int l = 1; l < 3; ++l) n.add_gather(d.M[l + 1], d.C[l + 1], d.KP[l]);
+  return n;
+}
+static long long conv_split_floats(const ConvDims& d) {
+  const SplitNeed n = conv_split_need(d);
+  return n.tiles > 0 ? al4(n.tiles) + n.slab : 0;
+}
 extern "C" long long dgvit_cnn_forward_scratch_floats(int B, int H, int W) {
   ConvDims d;
   if (make_conv_dims(B, H, W, d)) return -1;
-  return conv_cols_floats(d) + conv_wp_floats(d);
+  return conv_cols_floats(d) + conv_wp_floats(d) + conv_split_floats(d);
 }
 extern "C" long long dgvit_cnn_backward_scratch_floats(int B, int H, int W) {
   ConvDims d;
@@ -966,6 +981,17 @@ extern "C" int dgvit_cnn_forward(const float* img, const float* const* params, f
   float* wp[3] = {scratch + conv_cols_floats(d), nullptr, nullptr};
   wp[1] = wp[0] + al4(16 * 28);
   wp[2] = wp[1] + al4(64 * 400);
+  // in-launch split-K of the implicit-GEMM convolutions at small batches (conv3 at B = 32: 72 tiles of a 1600-deep GEMM on 256 CUs ran
+  // 60 us; cut into 12 k-slices 3-4x less): arrival counters (left clean by the kernel: one memset per forward) + slabs behind the weights
+  const SplitNeed csn = conv_split_need(d);
+  SplitBuf csk;
+  if (csn.tiles > 0) {
+    csk.counters = reinterpret_cast<int*>(wp[0] + conv_wp_floats(d));
+    csk.ncounters = (int)csn.tiles;
+    csk.slabs = wp[0] + conv_wp_floats(d) + al4(csn.tiles);
+    csk.slab_cap = csn.slab;
+    HIP_TRY(hipMemsetAsync(csk.counters, 0, sizeof(int) * csn.tiles, st));
+  }
   const float* in = img;
   for (int l = 0; l < 3; ++l) {
     TRY(weight_pack(params[2 * l], wp[l], d.C[l + 1], d.C[l], d.KP[l], 0, st));
@@ -985,6 +1011,7 @@ extern "C" int dgvit_cnn_forward(const float* img, const float* const* params, f
       p.g_wi = d.W[l] * C; p.g_hw = d.H[l] * d.W[l] * C; p.g_ph = 2; p.g_kh = 5; p.g_pw = pw; p.g_xs = 2 * C;
       p.g_gw = d.W[l + 1]; p.g_P = d.H[l + 1] * d.W[l + 1]; p.g_inv = inv; p.g_shift = shift;
     }
+    if (gather) csk.attach(p);
     TRY(gemm_f32(GEMM_NT, EPI_RELU, p, 1, st));   // relu(conv + bias), rows = next layer's NHWC input
     in = act[l + 1];
   }

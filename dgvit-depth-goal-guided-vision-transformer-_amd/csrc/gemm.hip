@@ -79,13 +79,15 @@ struct Fetch {
     unsigned bad[NV];   // MC: all ones when the slot's columns lie outside the matrix (OR-ed into the offset: no branch), else 0
     unsigned kstep;     // bytes to advance per k-tile
     int g_wi, g_pw, g_inv, g_shift;   // GATHER: image row pitch, window-row floats, 2^shift / pw + 1, shift
+    int g_k0;                         // GATHER: first k of this workgroup's k-range (a k-slice of a split tile starts past 0)
   };
 
   // GATHER: A is never materialised.  Row m of the patch matrix starts at pixel (b, hy * ph, wx * xs) of the image; element k of
   // the row is p1 = k / pw image rows further down and p2 = k % pw floats to the right (k / pw by multiply-shift; dgvit_api checks
   // that it is exact for every k < K).  Non-overlapping patches (xs = pw) and the strided 5x5 windows of the NHWC convolutions
   // (xs = stride * C, pw = KW * C) are the same arithmetic.  The descriptor covers the whole image buffer.
-  __device__ static __forceinline__ void plan_gather(Plan& pl, const GemmParams& p, int r0, int tid) {
+  __device__ static __forceinline__ void plan_gather(Plan& pl, const GemmParams& p, int r0, int kbeg, int tid) {
+    pl.g_k0 = kbeg;
     long long bytes = p.g_img_floats * 4;
     if (bytes > 0x7FFFFFFFll) bytes = 0x7FFFFFFFll;
     pl.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.g_img), 0, (int)bytes, 0x00020000);
@@ -142,7 +144,7 @@ struct Fetch {
     for (int i = 0; i < NV; ++i) {
       unsigned at;
       if constexpr (GATHER) {
-        const unsigned k = (unsigned)(t * BK + pl.kc[i]), p1 = (k * (unsigned)pl.g_inv) >> pl.g_shift, p2 = k - p1 * (unsigned)pl.g_pw;
+        const unsigned k = (unsigned)(pl.g_k0 + t * BK + pl.kc[i]), p1 = (k * (unsigned)pl.g_inv) >> pl.g_shift, p2 = k - p1 * (unsigned)pl.g_pw;
         at = (pl.off[i] + (p1 * (unsigned)pl.g_wi + p2) * 4u) | pl.bad[i];
       } else {
         at = (pl.off[i] + (unsigned)t * pl.kstep) | pl.bad[i];   // num_records <= 0x7FFFFFFF: all ones is out of range
@@ -422,7 +424,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
     // the fetch is branch-free (hardware range check), so loads, LDS writes and MFMAs share one basic block.
     typename FA::Plan pa;
     typename FB::Plan pb;
-    if constexpr (GATHER) FA::plan_gather(pa, p, m0, tid);
+    if constexpr (GATHER) FA::plan_gather(pa, p, m0, kbeg, tid);
     else FA::plan(pa, p.A, p.lda, m0, p.M, kbeg, p.K, tid);
     FB::plan(pb, p.B, p.ldb, n0, p.N, kbeg, p.K, tid);
     // prologue: the fetches of k-tiles 0 AND 1 are in flight together (one exposed round trip per output tile instead of two;
@@ -1372,7 +1374,7 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
   long long blocks = tiles;
   p.nsplit = 1;
   p.split_from = (int)tiles;
-  if (EPI != EPI_SPLITK && VEC == 4 && !GATHER && p.counters && p.slabs && p.evec && g_gemm_split) {
+  if (EPI != EPI_SPLITK && VEC == 4 && p.counters && p.slabs && p.evec && g_gemm_split) {   // (the gather loader takes k-slices too)
     const int occ = (int)std::min<size_t>(8, (160 * 1024) / lds);
     const GemmSplitPlan pl = split_plan(p.M, p.N, p.K, BM, BN, BK, occ);
     if (pl.nsplit > 1 && pl.slab_floats <= p.slab_capacity && tiles <= p.counter_capacity) {
@@ -1435,6 +1437,15 @@ int pick_tile(const GemmParams& p, int nsplit, bool vec4, int tile_hint, hipStre
 
 }  // namespace
 
+
+// the same for a GEMM whose A operand is gathered from an image (patch embedding, implicit-GEMM convolutions): always the 64 x 64 x 32 tile
+GemmSplitPlan gemm_split_plan_gather(int M, int N, int K) {
+  GemmSplitPlan none = {};
+  none.nsplit = 1;
+  if (M <= 0 || N <= 0 || K <= 0) return none;
+  const size_t lds = 2 * (size_t)(64 * (32 + 4) + 64 * (32 + 4)) * sizeof(float);
+  return split_plan(M, N, K, 64, 64, 32, (int)std::min<size_t>(8, (160 * 1024) / lds));
+}
 
 GemmSplitPlan gemm_split_plan(int layout, int M, int N, int K) {
   GemmSplitPlan none = {};

@@ -409,3 +409,27 @@ def test_stream_gemm_dma_sharing_is_bit_identical_to_the_round3_schedule(amd, M,
         ref = torch.nn.functional.gelu(ref)
     tol = 2e-2 if epi != 4 else 1e-3
     assert float((got - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------ split-K for the gathered (implicit-GEMM) forms
+@pytest.mark.parametrize("B,H,W", [(32, 128, 160), (2, 128, 160), (7, 84, 84), (1, 29, 33)])
+def test_implicit_gemm_convolutions_take_k_slices_at_small_batches(amd, B, H, W):
+    """conv2 / conv3 of the CNN critic run as implicit GEMMs (window gather in the A loader); at the shipped batch 32 conv3 is 72 tiles of a
+    1600-deep GEMM, now cut into k-slices inside the launch like the dense forms.  Same sums in another order: equal to the unsplit
+    launch (diagnostic knob) at 1e-5, and to torch's conv2d."""
+    from dgvit_amd import functional as F
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    shapes = [(16, 1, 5, 5), (16,), (64, 16, 5, 5), (64,), (256, 64, 5, 5), (256,)]
+    params = [(torch.randn(*s, generator=g) * (0.2 if len(s) > 1 else 0.05)).cuda() for s in shapes]
+    img = torch.rand(B, H, W, generator=g).cuda()
+    with torch.no_grad():
+        feat = F.cnn_features(img, params)
+        with knobs(gemm_split=0):
+            feat0 = F.cnn_features(img, params)
+        x = img[:, None]
+        for l in range(3):
+            x = torch.relu(torch.nn.functional.conv2d(x.double(), params[2 * l].double(), params[2 * l + 1].double(), stride=2))
+        ref = x.mean(dim=(2, 3)).float()
+    scale = max(1.0, float(ref.abs().max()))
+    assert float((feat - feat0).abs().max()) <= 1e-5 * scale
+    assert float((feat - ref).abs().max()) <= 1e-4 * scale
