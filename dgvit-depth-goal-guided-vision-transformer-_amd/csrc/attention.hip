@@ -297,20 +297,27 @@ __global__ void __launch_bounds__(128, 2) attn_fwd_pipe_kernel(const float* __re
     const float l = 0.f * __builtin_amdgcn_exp2f(-INFINITY - mn) + ts;
     f32x16 o[DT];
     zero_tiles<DT>(o);
+    // P V, eight keys (four k-steps) at a time: their V values are read from LDS as one batch in front of the eight MFMAs (one read and
+    // one wait per MFMA pair left the LDS latency exposed sixteen times per tile); a group of eight padding keys is skipped (P = 0)
+    auto pv_tile = [&](const f32x16& pt, int k0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (acc_row(r, 0) >= N) continue;
-      const float* vrow = Vs + acc_row(r, h) * SK + li;
+      for (int g4 = 0; g4 < 4; ++g4) {
+        if (k0 + 8 * g4 >= N) continue;
+        float vv[4][DT];
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[dt * 32], s0[r], o[dt], 0, 0, 0);
-    }
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const float* vrow = Vs + (k0 + acc_row(4 * g4 + r4, h)) * SK + li;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (32 + acc_row(r, 0) >= N) continue;
-      const float* vrow = Vs + (32 + acc_row(r, h)) * SK + li;
+          for (int dt = 0; dt < DT; ++dt) vv[r4][dt] = vrow[dt * 32];
+        }
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[dt * 32], s1[r], o[dt], 0, 0, 0);
-    }
+        for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[r4][dt], pt[4 * g4 + r4], o[dt], 0, 0, 0);
+      }
+    };
+    pv_tile(s0, 0);
+    pv_tile(s1, 32);
     if (qv) {
       const int b = item / H, hd = item % H;
       store_T<DH>(o, out + ((long long)b * N + q) * I + hd * DH, h, 1.f / l);
