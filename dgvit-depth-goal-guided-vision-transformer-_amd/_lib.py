@@ -133,6 +133,7 @@ DIAG_SIGNATURES = {
     "dgvit_set_gemm_bf16_l2_budget_kb": (None, [_I]),
     "dgvit_set_attention_bwd_single_pass": (None, [_I]),
     "dgvit_set_attention_single_query": (None, [_I]),
+    "dgvit_set_gemm_wgrad_slice_major": (None, [_I]),
     "dgvit_attention_forward_queries": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dgvit_attention_backward_queries": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dgvit_set_gemm_bf16_mfma16": (None, [_I]),

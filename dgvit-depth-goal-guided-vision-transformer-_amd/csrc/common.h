@@ -90,6 +90,7 @@ struct GemmParams {
   int* counters; float* slabs;
   long long slab_capacity; int counter_capacity;   // floats / ints available behind `slabs` / `counters`
   int split_from, nsplit, kchunk_split;            // filled in at launch
+  int zsplit;                                      // EPI_SPLITK: k-slices of the launch when they are folded into blockIdx.x (0: blockIdx.z)
   // fused LayerNorm of the output rows (EPI_STORE, N == the tile's width: the whole row is in one tile; the encoder uses it for
   // D <= 64): y[m] = LN(C[m]) * g + b with row stride ln_ld, mean / rstd per logical row; ln_y == nullptr: off
   const float* ln_g; const float* ln_b; float* ln_y; float* ln_mean; float* ln_rstd; long long ln_ld; float ln_eps;

@@ -18,7 +18,7 @@ long long* g_gemm_stamps = nullptr;
 int g_gemm_stamp_capacity = 0;
 long long g_gemm_persist_launches = 0;
 int g_group_reduce = 1, g_ln_fusion = 1, g_conv_gather = 1, g_small_path = 0, g_small_path_max_rows = 4160, g_block_path = 1, g_block_path_max_rows = 4160, g_gelu_grad_store = 1, g_block_fuse = 2;
-int g_gemm_bf16_tile_hint = 0, g_gemm_bf16_m16 = 1, g_gemm_bf16_group_m = 8, g_attn_bwd64 = 1, g_attn_q1 = 1, g_gemm_bf16_l2_budget_kb = 2048;
+int g_gemm_bf16_tile_hint = 0, g_gemm_bf16_m16 = 1, g_gemm_bf16_group_m = 8, g_attn_bwd64 = 1, g_attn_q1 = 1, g_gemm_zfold = 1, g_gemm_bf16_l2_budget_kb = 2048;
 long long* g_gemm_bf16_stamps = nullptr;
 long long* g_block_stamps = nullptr;
 int g_block_stamp_layer = -1, g_block_stamp_now = 1;
@@ -334,6 +334,7 @@ extern "C" void dgvit_set_gemm_bf16_tile(int tile) { g_gemm_bf16_tile_hint = til
 extern "C" void dgvit_set_gemm_bf16_mfma16(int on) { g_gemm_bf16_m16 = on ? 1 : 0; }
 extern "C" void dgvit_set_attention_bwd_single_pass(int on) { g_attn_bwd64 = on ? 1 : 0; }
 extern "C" void dgvit_set_attention_single_query(int on) { g_attn_q1 = on ? 1 : 0; }
+extern "C" void dgvit_set_gemm_wgrad_slice_major(int on) { g_gemm_zfold = on ? 1 : 0; }
 extern "C" int dgvit_attention_forward_queries(const float* qkv, float* out, float* lse, int B, int N, int H, int dh, int nq, void* stream) {
   return attention_fwd(qkv, out, lse, B, N, H, dh, nq, (hipStream_t)stream);
 }

@@ -298,6 +298,11 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   // stored factor instead of evaluating erf and exp per element in its epilogue (same values, bit for bit)
   constexpr bool TWO_OUT = EPI == EPI_GELU2 || EPI == EPI_GELU2D;
   constexpr bool ACT_GRAD = EPI == EPI_DGELU || EPI == EPI_DMUL;
+  // Direct-epilogue output stores of the two-output forward (fc1: gelu + gelu') and of the gelu'-scaled data gradient are NON-TEMPORAL: 10 MB
+  // of output per round of tiles streamed through each 4 MB L2 and evicted the A panels the column tiles share -- fc1 forward read 121.6 MB per
+  // launch for 28 MB of operands, the fc2 data gradient 346 for 238 (rocprofv3 FETCH_SIZE by launch, profiles/r04_g_gemm_traffic_by_launch.txt);
+  // with aux 2 (no L2 allocation) 43.2 and 263.5 MB.  Step time unchanged (12.52 vs 12.53 ms interleaved with the bit on every direct epilogue).
+  constexpr bool NT_STORES = TWO_OUT || ACT_GRAD;
   constexpr int WM = BM / T::WVM, WN = BN / T::WVN, TM = WM / 32, TN = WN / 32;
   static_assert(WM % 32 == 0 && WN % 32 == 0 && BM <= NT, "bad wave layout");
   constexpr int A_TILE = AKC ? BM * (BK + 4) : BK * (BM + 4);
@@ -319,7 +324,17 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   // chip has workgroup slots (small batches: T = 65 ... 2080 rows, K = 2048), and the last partial round of a large grid
   // (25600 x 256 outputs = 1600 tiles = 6.25 per CU: the 64 left-over tiles become 256 quarter-tiles).
   int tile, zs = 0, nz = 1;
-  if (EPI != EPI_SPLITK && p.nsplit > 1 && (int)blockIdx.x >= p.split_from) {
+  // Weight gradients (EPI_SPLITK): (tile, k-slice) pairs in ONE grid dimension, k-slice major, each XCD a contiguous chunk of that order.
+  // An XCD then works on a few k-slices of EVERY output tile: the rows of dY and X in those slices are read once, by the one L2 that serves
+  // all their tiles.  (Round 1-3 gave an XCD a few tiles and ALL their k-slices -- grid (tiles, 1, slices), XCD = blockIdx.x % 8: every XCD
+  // streamed the whole of X, and the tiles sharing a dY block sat on one XCD but in different slices' dispatch order: 532 MB read per
+  // fc1 / fc2 weight-gradient launch for 236 MB of operands, rocprofv3 FETCH_SIZE by launch, profiles/r04_g_gemm_traffic_by_launch.txt.)
+  int zslice = blockIdx.z;
+  if (EPI == EPI_SPLITK && p.zsplit > 1) {
+    const int ntile = tiles_m * tiles_n, w = xcd_remap(blockIdx.x, ntile * p.zsplit);
+    zslice = w / ntile;
+    tile = w - zslice * ntile;
+  } else if (EPI != EPI_SPLITK && p.nsplit > 1 && (int)blockIdx.x >= p.split_from) {
     const int r = (int)blockIdx.x - p.split_from;
     tile = p.split_from + r / p.nsplit;
     zs = r % p.nsplit;
@@ -328,7 +343,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
     tile = xcd_remap(blockIdx.x, EPI != EPI_SPLITK && p.nsplit > 1 ? p.split_from : tiles_m * tiles_n);
   }
   const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-  const int kbeg = nz > 1 ? zs * p.kchunk_split : blockIdx.z * p.kchunk;
+  const int kbeg = nz > 1 ? zs * p.kchunk_split : zslice * p.kchunk;
   const int kend = min(p.K, kbeg + (nz > 1 ? p.kchunk_split : p.kchunk));
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 
@@ -565,6 +580,16 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
               else acc[i][j][r] = sv > 0.f ? acc[i][j][r] : 0.f;
             }
       }
+      // output stores: ordinary, or non-temporal (aux 2: no allocation in the L2) for NT_STORES epilogues -- and for every direct epilogue under
+      // diagnostic bit 16 of dgvit_set_gemm_diagnostics
+      auto st32 = [&](unsigned v, __amdgpu_buffer_rsrc_t rs, unsigned off) {
+        if (NT_STORES || DIAG_BIT(p, 16)) __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, 0);
+      };
+      auto st64 = [&](u32x2 v, __amdgpu_buffer_rsrc_t rs, unsigned off) {
+        if (NT_STORES || DIAG_BIT(p, 16)) __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 2);
+        else __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 0);
+      };
       const __amdgpu_buffer_rsrc_t cr = tile_rsrc(p.C, p.ldc);
       __amdgpu_buffer_rsrc_t c2r = cr;
       if (TWO_OUT) c2r = tile_rsrc(p.C2, p.ldc2);
@@ -586,12 +611,12 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
               if constexpr (EPI == EPI_GELU2D) {
                 float gl, gd;
                 gelu_erf_both(v[j], gl, gd);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gd), cr, eoff(i, j, r, p.ldc), 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gl), c2r, eoff(i, j, r, p.ldc), 0, 0);
+                st32(__builtin_bit_cast(unsigned, gd), cr, eoff(i, j, r, p.ldc));
+                st32(__builtin_bit_cast(unsigned, gl), c2r, eoff(i, j, r, p.ldc));
               } else {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[j]), cr, eoff(i, j, r, p.ldc), 0, 0);
+                st32(__builtin_bit_cast(unsigned, v[j]), cr, eoff(i, j, r, p.ldc));
                 if (EPI == EPI_GELU2)
-                  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, gelu_erf(v[j])), c2r, eoff(i, j, r, p.ldc), 0, 0);
+                  st32(__builtin_bit_cast(unsigned, gelu_erf(v[j])), c2r, eoff(i, j, r, p.ldc));
               }
             }
           } else {
@@ -602,19 +627,19 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
               gelu_erf_both(v[1], gl1, gd1);
               w[0] = __builtin_bit_cast(unsigned, gd0);
               w[1] = __builtin_bit_cast(unsigned, gd1);
-              __builtin_amdgcn_raw_buffer_store_b64(w, cr, eoff(i, 0, r, p.ldc), 0, 0);
+              st64(w, cr, eoff(i, 0, r, p.ldc));
               w[0] = __builtin_bit_cast(unsigned, gl0);
               w[1] = __builtin_bit_cast(unsigned, gl1);
-              __builtin_amdgcn_raw_buffer_store_b64(w, c2r, eoff(i, 0, r, p.ldc), 0, 0);
+              st64(w, c2r, eoff(i, 0, r, p.ldc));
               continue;
             }
             w[0] = __builtin_bit_cast(unsigned, v[0]);
             w[1] = __builtin_bit_cast(unsigned, v[1]);
-            __builtin_amdgcn_raw_buffer_store_b64(w, cr, eoff(i, 0, r, p.ldc), 0, 0);
+            st64(w, cr, eoff(i, 0, r, p.ldc));
             if (EPI == EPI_GELU2) {
               w[0] = __builtin_bit_cast(unsigned, gelu_erf(v[0]));
               w[1] = __builtin_bit_cast(unsigned, gelu_erf(v[1]));
-              __builtin_amdgcn_raw_buffer_store_b64(w, c2r, eoff(i, 0, r, p.ldc), 0, 0);
+              st64(w, c2r, eoff(i, 0, r, p.ldc));
             }
           }
         }
@@ -629,7 +654,7 @@ __global__ void __launch_bounds__(T::NT, T::MINB) gemm_f32_kernel(const GemmPara
   // ---- epilogue ------------------------------------------------------------------------------------
   float* Cz = p.C;
   if (EPI == EPI_SPLITK) {
-    Cz += (long long)blockIdx.z * p.slab_stride;
+    Cz += (long long)zslice * p.slab_stride;
     if (p.colsum && n0 == 0 && tid < BM && m0 + tid < p.M) Cz[(long long)p.M * p.N + m0 + tid] = bsum;
   }
   // Fused LayerNorm of a finished output row (p.ln_y; launch checks N == BN, so the BN / 4 lanes tid % C4 of a wave hold the row).
@@ -1395,6 +1420,11 @@ int launch(const GemmParams& p0, int nsplit, hipStream_t stream) {
   }
 #endif
   dim3 grid((unsigned)blocks, 1, (unsigned)nsplit);
+  p.zsplit = 0;
+  if (EPI == EPI_SPLITK && nsplit > 1 && g_gemm_zfold && blocks * nsplit < (1ll << 31)) {   // k-slices folded into blockIdx.x (see the kernel)
+    p.zsplit = nsplit;
+    grid = dim3((unsigned)(blocks * nsplit), 1, 1);
+  }
   const int slot = profile_begin(PROF_GEMM, 2.0 * p.M * p.N * p.K, stream);
   hipLaunchKernelGGL(kern, grid, dim3(T::NT), lds + (size_t)g_gemm_lds_pad, stream, p);
   profile_end(slot, stream);

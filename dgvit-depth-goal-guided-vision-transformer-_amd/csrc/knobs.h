@@ -46,6 +46,7 @@ DGVIT_KNOB(int, g_gemm_bf16_group_m, 8)         // row panels per walk group of 
 DGVIT_KNOB(int, g_gemm_bf16_l2_budget_kb, 2048)  // stream GEMM: L2 bytes a column block's B panels may take (0 = the round-3 group_m walk)
 DGVIT_KNOB(long long*, g_gemm_bf16_stamps, nullptr)
 DGVIT_KNOB(int, g_attn_bwd64, 1)                // single-pass fp32 attention backward for 32 < N <= 64
+DGVIT_KNOB(int, g_gemm_zfold, 1)                // weight-gradient GEMMs: k-slices folded into blockIdx.x, k-slice major per XCD (0: grid z)
 DGVIT_KNOB(int, g_attn_q1, 1)                   // one-query (token 0) fp32 attention forward / backward on plain FMAs for N <= 64
 #ifdef DGVIT_DIAG
 extern long long g_gemm_persist_launches;       // launches that took the pipelined kernel

@@ -88,6 +88,9 @@ void dgvit_set_gemm_bf16_l2_budget_kb(int kb);
 void dgvit_set_attention_bwd_single_pass(int on);
 /* 0: a one-query attention (the last block's token 0) runs on the MFMA tile kernels as before round 4; 1 (default): attn_q1_*_kernel */
 void dgvit_set_attention_single_query(int on);
+/* A/B knob: 1 (default) the weight-gradient GEMMs deal (tile, k-slice) pairs to the XCDs k-slice major (an XCD reads its slices of dY and X
+ * once); 0 the round 1-3 grid (tiles, 1, slices): an XCD owns a few tiles and all their slices.  Bit-identical results. */
+void dgvit_set_gemm_wgrad_slice_major(int on);
 /* dgvit_attention_forward / _backward (dgvit_hip.h) for the first nq query tokens only, as the encoder's last block calls them with nq = 1
  * (GoalFormer.py:167 reads x[:, 0]): rows >= nq of out / lse / dq are not written, dk and dv cover every key */
 int dgvit_attention_forward_queries(const float* qkv, float* out, float* lse, int B, int N, int H, int dh, int nq, void* stream);

@@ -23,7 +23,7 @@ _KNOBS = {
     "small_batch_path": ("dgvit_set_small_batch_path", (0, 0)), "block_path": ("dgvit_set_block_path", (1, 4160)), "gelu_grad_store": ("dgvit_set_gelu_grad_store", (1,)), "block_fuse": ("dgvit_set_block_fuse", (2,)), "gemm_bf16_tile": ("dgvit_set_gemm_bf16_tile", (0,)),
     "gemm_bf16_mfma16": ("dgvit_set_gemm_bf16_mfma16", (1,)), "gemm_bf16_group_m": ("dgvit_set_gemm_bf16_group_m", (8,)),
     "gemm_bf16_l2_budget_kb": ("dgvit_set_gemm_bf16_l2_budget_kb", (2048,)),
-    "attention_bwd_single_pass": ("dgvit_set_attention_bwd_single_pass", (1,)), "attention_single_query": ("dgvit_set_attention_single_query", (1,)), "gemm_lds_pad": ("dgvit_set_gemm_lds_pad", (0,)),
+    "attention_bwd_single_pass": ("dgvit_set_attention_bwd_single_pass", (1,)), "attention_single_query": ("dgvit_set_attention_single_query", (1,)), "gemm_wgrad_slice_major": ("dgvit_set_gemm_wgrad_slice_major", (1,)), "gemm_lds_pad": ("dgvit_set_gemm_lds_pad", (0,)),
 }
 
 

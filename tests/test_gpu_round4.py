@@ -433,3 +433,31 @@ def test_implicit_gemm_convolutions_take_k_slices_at_small_batches(amd, B, H, W)
     scale = max(1.0, float(ref.abs().max()))
     assert float((feat - feat0).abs().max()) <= 1e-5 * scale
     assert float((feat - ref).abs().max()) <= 1e-4 * scale
+
+
+# ------------------------------------------------------------------------------------------------ weight gradients: k-slice-major block order
+def test_weight_gradient_slice_major_block_order_is_bit_identical(amd):
+    """gemm.hip, EPI_SPLITK: (tile, k-slice) pairs are dealt to the XCDs k-slice major (an XCD reads its slices of dY and X once) instead of
+    grid (tiles, 1, slices).  Only WHICH workgroup computes a slab changes: every gradient of a training step is bit-identical."""
+    cfg = O.GoTConfig(image=(84, 84), patch=(12, 12), dim=256, depth=2, heads=8)
+    m = amd.GoTPolicy(2, 2, cfg.depth, cfg.heads, cfg.dim, image_size=cfg.image, patch_size=cfg.patch)
+    m.load_state_dict(O.make_params(O.policy_param_spec(cfg), 77), strict=True)
+    m = m.cuda().train()
+    img, pstate, _, _ = (t.cuda() for t in O.make_inputs(cfg, 96, 77))
+
+    def run():
+        for q in m.parameters():
+            q.grad = None
+        torch.manual_seed(5)
+        mean, log_std = m([img, pstate])
+        ((mean ** 2).mean() + (log_std ** 2).mean()).backward()
+        torch.cuda.synchronize()
+        return {k: q.grad.clone() for k, q in m.named_parameters() if q.grad is not None}
+
+    with knobs(force_diag=True):
+        a = run()
+    with knobs(gemm_wgrad_slice_major=0):
+        b = run()
+    assert a.keys() == b.keys() and len(a) > 20
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
