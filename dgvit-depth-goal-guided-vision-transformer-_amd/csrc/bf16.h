@@ -53,7 +53,8 @@ struct GemmBf16Params {
   int ksplit, kchunk;           // ksplit > 1: K is cut into ksplit slices of kchunk (multiple of 32); slice z writes C + z * slab_stride
   long long slab_stride;        //             (BEPI_F32_PLAIN only; the slabs are summed by reduce_slabs)
   int group_m;                  // row panels per walk group (0 = default); see tile_mn in gemm_bf16_ring_kernel
-  int col_blocks;               // stream kernel: column blocks of the tile walk (set at launch; 0 = the older group_m walk)
+  int col_blocks;
+  int slice_major;              // ring kernel, split-K: virtual tiles k-slice major (1) or tile major (0, the order until round 4)               // stream kernel: column blocks of the tile walk (set at launch; 0 = the older group_m walk)
   int stagger; long long stagger_cycles;   // stream kernel: start phases of the workgroups and cycles between them (set at launch)
 #ifdef DGVIT_DIAG
   long long* diag_stamps;   // stream kernel, timing variant 512: [workgroup][wave][tile < 8][8] s_memtime stamps (tools/bf16_stream_stamps.py)

@@ -248,8 +248,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   const int li = lane & 31, h = lane >> 5;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int wr = wave / T::WN, wc = wave % T::WN;
-  // split-K (weight gradients: few output tiles, very long K): virtual tile v -> (output tile v / S, k-slice v % S);
-  // slice z covers k in [z * kchunk, min(K, (z + 1) * kchunk)) and writes its partial sums to slab z of C
+  // split-K (weight gradients: few output tiles, very long K): virtual tile v -> (k-slice v / tiles, output tile v % tiles), K-SLICE MAJOR:
+  // the contiguous chunk of virtual tiles an XCD walks is then a few k-slices of EVERY output tile, so the rows of dY and X in those
+  // slices are fetched once, by the one L2 that serves all their tiles.  (Until round 4 the order was tile major -- an XCD owned a few
+  // tiles and all their slices, and every XCD streamed the whole of X: the fp32 twin of this kernel read 2.3x its operands that way,
+  // profiles/r04_g_gemm_traffic_by_launch.txt.)  Slice z covers k in [z * kchunk, min(K, (z + 1) * kchunk)) and writes its partial
+  // sums to slab z of C
   const int S = p.ksplit > 1 ? p.ksplit : 1;
   const int kchunk = S > 1 ? p.kchunk : ((p.K + 31) & ~31);
   // tile order inside an XCD's chunk: groups of GROUP_M row panels walked column by column, so that the ~32 tiles an XCD
@@ -264,6 +268,10 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
     n0 = (within / rows) * BN;
   };
   auto slice_len = [&](int z) { const int rem = p.K - z * kchunk; return rem < kchunk ? rem : kchunk; };
+  const int tiles_mn = tiles_m * tiles_n;
+  const bool smaj = p.slice_major != 0;
+  auto v_slice = [&](int vt) { return S > 1 ? (smaj ? vt / tiles_mn : vt % S) : 0; };
+  auto v_tile = [&](int vt) { return S > 1 ? (smaj ? vt - (vt / tiles_mn) * tiles_mn : vt / S) : vt; };
 
   // ---- load side: runs D k-tiles ahead of the compute side, across tile boundaries ---------------------------
   // one DMA instruction fills 16 rows x 64 bytes: lane -> row lane >> 2, physical chunk lane & 3, which holds logical
@@ -282,10 +290,10 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   bool la_ok = true, lb_ok = true;   // TN: this lane's 8 columns lie inside the matrix (M, N % 8 == 0)
   __amdgpu_buffer_rsrc_t rsA, rsB;
   auto set_load_tile = [&](int v) {
-    const int vt = xcd_chunk(v, ntiles), tile = vt / S, k0 = (vt % S) * kchunk;
+    const int vt = xcd_chunk(v, ntiles), tile = v_tile(vt), k0 = v_slice(vt) * kchunk;
     int m0, n0;
     tile_mn(tile, m0, n0);
-    lklen = slice_len(vt % S);
+    lklen = slice_len(v_slice(vt));
     lnkt = (lklen + 31) / 32;
     long long abytes, bbytes;
     if (TN) {
@@ -396,7 +404,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   int ctile = blockIdx.x, ct = 0, cslot = 0, since_epi = D, ntile_done = 0;
-  int cnkt = (slice_len(xcd_chunk(ctile, ntiles) % S) + 31) / 32;
+  int cnkt = (slice_len(v_slice(xcd_chunk(ctile, ntiles))) + 31) / 32;
   long long st0 = 0;
   if constexpr (STAMP) st0 = __builtin_amdgcn_s_memtime();
 
@@ -484,7 +492,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
     long long st1 = 0;
     if constexpr (STAMP) st1 = __builtin_amdgcn_s_memtime();
     {
-      const int vt = xcd_chunk(ctile, ntiles), tile = vt / S;
+      const int vt = xcd_chunk(ctile, ntiles), tile = v_tile(vt);
       int m0, n0;
       tile_mn(tile, m0, n0);
       const int gn = n0 + wc * WTN + ecol;
@@ -493,7 +501,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
       const long long crow0 = p.c_rgrp > 0 ? m0 + m0 / p.c_rgrp + 1 : m0;
       constexpr int CES = (EPI == BEPI_F32 || EPI == BEPI_F32_PLAIN) ? 4 : 2;
       const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
-          reinterpret_cast<unsigned char*>(p.C) + ((long long)(vt % S) * p.slab_stride + crow0 * p.ldc + n0) * CES, 0, (int)DGVIT_BUF_OOB,
+          reinterpret_cast<unsigned char*>(p.C) + ((long long)v_slice(vt) * p.slab_stride + crow0 * p.ldc + n0) * CES, 0, (int)DGVIT_BUF_OOB,
           0x00020000);
       __amdgpu_buffer_rsrc_t rsX = rsC;   // second operand of the epilogue: residual (fp32) / pre-activation copy / aux (bf16)
       if (EPI == BEPI_F32 && p.res)
@@ -597,7 +605,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_ring_kernel(const GemmBf16Param
     ct = 0;
     since_epi = 0;
     ctile += gridDim.x;
-    if (ctile < ntiles) cnkt = (slice_len(xcd_chunk(ctile, ntiles) % S) + 31) / 32;
+    if (ctile < ntiles) cnkt = (slice_len(v_slice(xcd_chunk(ctile, ntiles))) + 31) / 32;
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   wait_vmcnt<0>();   // the trailing (all-zero) LDS-DMAs must land before the workgroup gives its LDS back
@@ -636,6 +644,7 @@ template <class T, int EPI, bool RING>
 int launch(const GemmBf16Params& p_in, hipStream_t st) {
   GemmBf16Params p = p_in;
   if (p.group_m <= 0) p.group_m = g_gemm_bf16_group_m > 0 ? g_gemm_bf16_group_m : 8;
+  p.slice_major = g_gemm_zfold;
   const long long tiles = (long long)((p.M + T::BM - 1) / T::BM) * ((p.N + T::BN - 1) / T::BN);
   DGVIT_CHECK_ARG(tiles < (1ll << 30), "gemm_bf16: too many tiles");
   if constexpr (RING) {
