@@ -1,4 +1,5 @@
-// Fused multi-head self-attention for short sequences (N <= 224 tokens), fp32 on v_mfma_f32_32x32x2_f32.
+// Fused multi-head self-attention for short sequences (N <= 288 tokens: K and V of one (frame, head) stay in the 160 KB LDS), fp32 on
+// v_mfma_f32_32x32x2_f32.
 // Restates Attention.forward, GoalFormer.py:73-81: per (frame, head)  softmax(q k^T * dh^-1/2) v, reading q/k/v
 // straight out of the (B, N, 3*I) to_qkv output ([q heads | k heads | v heads], 64 columns per head) and writing
 // the merged-head (B, N, I) layout -- the reference's two einops rearrange copies never materialise.
@@ -859,7 +860,7 @@ int launch_q1_bwd(const float* qkv, const float* o, const float* dout, const flo
   return DGVIT_OK;
 }
 
-constexpr int MAX_TOKENS = 224;
+constexpr int MAX_TOKENS = 288;   // 2 * 288 * 68 floats (K, V images at dim_head 64) + 2 * 288 (lse, delta) = 159.0 KB of the 160 KB LDS
 
 template <int DH, int NW, int NKT_CT>
 int launch_fwd(const float* qkv, float* out, float* lse, int B, int N, int H, float scale, int nq, hipStream_t stream) {
@@ -920,7 +921,7 @@ int attention_fwd(const float* qkv, float* out, float* lse, int B, int N, int H,
   DGVIT_CHECK_ARG(qkv && out && B > 0 && N > 0 && H > 0, "attention_fwd: bad arguments");
   DGVIT_CHECK_ARG((long long)B * H < (1ll << 31), "attention_fwd: B*H too large");
   DGVIT_CHECK_ARG(nq >= 1 && nq <= N, "attention_fwd: bad query count");
-  DGVIT_CHECK_ARG(N <= MAX_TOKENS && (dh == 64 || dh == 32), "attention_fwd: unsupported dim_head=%d / tokens=%d (dim_head 64 or 32, N <= 224)", dh, N);
+  DGVIT_CHECK_ARG(N <= MAX_TOKENS && (dh == 64 || dh == 32), "attention_fwd: unsupported dim_head=%d / tokens=%d (dim_head 64 or 32, N <= 288)", dh, N);
   const float scale = 1.0f / sqrtf((float)dh);
   if (g_attn_q1 && nq == 1 && N <= 64) {                               // token 0 only (the last block): one wave per (frame, head)
     if (dh == 64) return launch_q1_fwd<64>(qkv, out, lse, B, N, H, scale, stream);

@@ -191,7 +191,7 @@ int make_dims(const dgvit_config* c, int batch, Dims& d) {
   d.pool_mean = c->pool_mean ? 1 : 0;
   d.proj = !(d.H == 1 && d.dh == d.D);
   d.T = (long long)batch * d.N;
-  DGVIT_CHECK_ARG(d.N <= 224, "tokens N=%d exceeds the fused-attention limit (224)", d.N);
+  DGVIT_CHECK_ARG(d.N <= 288, "tokens N=%d exceeds the fused-attention limit (288)", d.N);
   DGVIT_CHECK_ARG(d.T < (1ll << 31) && d.T * (long long)(3 * d.I > d.M ? 3 * d.I : d.M) < (1ll << 40), "batch too large");
   return DGVIT_OK;
 }

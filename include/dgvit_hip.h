@@ -44,7 +44,7 @@ int dgvit_device_count(void);
 /* ----------------------------------------------------------------------------------------------
  * Encoder shape = the GoT constructor arguments (GoalFormer.py:124-154).  patch_h/patch_w are honoured
  * (the reference hard-wires 16x20, GoalFormer.py:137-139).  dim_head must be 64 or 32; tokens
- * N = (image_h/patch_h)*(image_w/patch_w) + 1 <= 224.
+ * N = (image_h/patch_h)*(image_w/patch_w) + 1 <= 288.
  * -------------------------------------------------------------------------------------------- */
 typedef struct dgvit_config {
   int image_h, image_w;
@@ -216,7 +216,7 @@ long long dgvit_rmsnorm_backward_scratch_floats(int rows, int D);
 int dgvit_rmsnorm_backward(const float* dy, const float* x, long long ldx, const float* g, float* dx, long long lddx,
                            float* dg, float* scratch, long long scratch_floats, int rows, int D, void* stream);
 
-/* Attention core (GoalFormer.py:73-81): qkv (B, N, 3*H*dh) -> out (B, N, H*dh); scale dh^-1/2; N <= 224, dh 64 or 32.
+/* Attention core (GoalFormer.py:73-81): qkv (B, N, 3*H*dh) -> out (B, N, H*dh); scale dh^-1/2; N <= 288, dh 64 or 32.
  * lse (B, H, N): base-2 log-sum-exp of every scaled score row, written by forward (NULL = not kept) and needed by
  * backward, which recomputes the probabilities from it tile by tile (nothing of size N x N is ever stored). */
 int dgvit_attention_forward(const float* qkv, float* out, float* lse, int B, int N, int H, int dh, void* stream);

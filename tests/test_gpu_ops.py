@@ -129,7 +129,8 @@ def _attn_ref(qkv, H, dh):
 
 @pytest.mark.parametrize("B,N,H,dh", [(3, 50, 8, 64), (2, 65, 4, 64), (2, 7, 2, 32), (1, 32, 1, 64), (2, 37, 2, 64), (1, 145, 2, 64),
                                       (1, 197, 3, 64), (2, 64, 2, 32), (1, 1, 2, 64), (1, 224, 1, 64), (2, 100, 3, 32), (1, 96, 2, 64),
-                                      (2, 33, 2, 64), (1, 64, 3, 64), (2, 50, 2, 32), (1, 63, 1, 32)])
+                                      (2, 33, 2, 64), (1, 64, 3, 64), (2, 50, 2, 32), (1, 63, 1, 32),
+                                      (2, 225, 2, 64), (1, 257, 3, 64), (2, 288, 2, 64), (1, 257, 2, 32), (1, 288, 1, 32)])
 def test_attention_fwd_bwd(F, B, N, H, dh):
     qkv = rnd(B, N, 3 * H * dh, seed=N)
     dout = rnd(B, N, H * dh, seed=N + 1)

@@ -461,3 +461,41 @@ def test_weight_gradient_slice_major_block_order_is_bit_identical(amd):
     assert a.keys() == b.keys() and len(a) > 20
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+# ------------------------------------------------------------------------------------------------ more than 224 tokens
+@pytest.mark.parametrize("image,patch,heads,dense_last", [((224, 224), (14, 14), 2, False), ((224, 224), (14, 14), 1, True), ((136, 168), (8, 8), 4, False)])
+def test_encoder_with_up_to_288_tokens_matches_the_oracle(amd, image, patch, heads, dense_last):
+    """GoT on 224x224 frames with 14x14 patches has 257 tokens: the fp32 attention kernels keep K and V of one (frame, head) in LDS up to
+    288 tokens (round 3 refused N > 224).  Outputs 1e-4, gradients 2e-3 against the CPU oracle, token-0 and dense last block; the third
+    case (136x168 @ 8: 17 * 21 + 1 = 358 tokens) must still be refused, with the limit in the message."""
+    cfg = O.GoTConfig(image=image, patch=patch, dim=64, depth=2, heads=heads, dim_head=64, mlp_dim=128)
+    if cfg.tokens > 288:
+        m = _build_got(amd, cfg).cuda().eval()
+        with pytest.raises(Exception, match="288"):
+            m(torch.rand(1, *image, device="cuda"), torch.randn(1, cfg.dim, device="cuda"))
+        return
+    assert cfg.tokens == 257
+    params = O.make_params(O.got_param_spec(cfg, prefix=""), 21)
+    m = _build_got(amd, cfg)
+    m.load_state_dict(params, strict=True)
+    m = m.cuda().eval().set_schedule(dense_last_block=dense_last)
+    B = 3
+    img, _, _, _ = O.make_inputs(cfg, B, 21)
+    goal = torch.randn(B, cfg.dim, generator=torch.Generator().manual_seed(4))
+    wout = torch.randn(B, cfg.dim, generator=torch.Generator().manual_seed(5))
+    gg = goal.cuda().requires_grad_(True)
+    feat = m(img.cuda(), gg)
+    (feat * wout.cuda()).sum().backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    g2 = goal.clone().requires_grad_(True)
+    ref = O.got_forward(p, img, g2, cfg, prefix="")
+    (ref * wout).sum().backward()
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=OUT_TOL)
+    np.testing.assert_allclose(gg.grad.cpu().numpy(), g2.grad.numpy(), rtol=GRAD_RTOL, atol=1e-4)
+    for k, q in m.named_parameters():
+        if p[k].grad is None:
+            continue
+        r = p[k].grad
+        err = float((q.grad.cpu() - r).norm() / (r.norm() + 1e-12))
+        assert err < GRAD_RTOL, (k, err)
