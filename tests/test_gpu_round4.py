@@ -325,7 +325,9 @@ def test_stored_gelu_derivative_is_bit_identical_to_the_backward_epilogue_form(a
 
 
 # ------------------------------------------------------------------------------------------------ one-query attention (the last block's token 0)
-@pytest.mark.parametrize("B,N,H,dh", [(37, 50, 8, 64), (5, 37, 4, 64), (3, 64, 2, 64), (9, 17, 4, 32), (2, 1, 1, 64), (130, 50, 8, 32), (4, 33, 1, 64)])
+@pytest.mark.parametrize("B,N,H,dh", [(37, 50, 8, 64), (5, 37, 4, 64), (3, 64, 2, 64), (9, 17, 4, 32), (2, 1, 1, 64), (130, 50, 8, 32), (4, 33, 1, 64),
+                                      (3, 2, 3, 32), (2, 3, 2, 64), (7, 5, 1, 32), (1, 8, 5, 64), (2, 31, 2, 32), (3, 32, 3, 64), (2, 48, 2, 32), (1, 63, 3, 64),
+                                      (1025, 50, 4, 64)])
 def test_single_query_attention_matches_torch_and_the_tile_kernels(amd, B, N, H, dh):
     """GoalFormer.py:167 reads x[:, 0]: the last block's attention has one query row per (frame, head).  attn_q1_fwd / attn_q1_bwd (plain
     fp32 FMAs, a wave per (frame, head)) against torch autograd on the same row, and against the MFMA tile kernels they replace."""
